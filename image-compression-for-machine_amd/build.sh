@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libicm_hip.so for gfx950 (MI355X). Cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+mkdir -p lib build
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+objs=""
+for f in conv_igemm conv_wgrad pointwise entropy winattn; do
+  if [ ! -f build/$f.o ] || [ csrc/$f.hip -nt build/$f.o ] || [ csrc/icm_common.h -nt build/$f.o ] || [ ../include/icm_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c csrc/$f.hip -o build/$f.o &
+  fi
+  objs="$objs build/$f.o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o lib/libicm_hip.so $objs
+echo "built lib/libicm_hip.so"

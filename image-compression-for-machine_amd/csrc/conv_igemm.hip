@@ -1,0 +1,540 @@
+// Implicit-GEMM convolution family on f32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// One kernel serves conv fwd, conv dgrad, convT fwd, convT dgrad, 1x1 convs / Linear layers and the
+// GDN channel contraction (reference call sites: include/icm_hip.h).  GEMM view per launch:
+//     D[co][pixel] = sum_{tap, ci} Wp[tap][ci][co] * patch[ci][pixel + tap]
+//   * M = output channels (MFMA A operand, rows), N = pixels (MFMA B operand, columns) so that the
+//     32 lanes of a half-wave hold 32 consecutive pixels of one channel plane: NCHW loads and stores
+//     are 128-B coalesced with no transposes anywhere;
+//   * the input patch of the block's pixel tile (8 input channels per K-chunk, halo included) is
+//     staged once into LDS and re-read for every tap (25x reuse for 5x5) -- activations are never
+//     im2col-expanded in HBM or L2; stride-2 patches are stored column-parity-split so the B-fragment
+//     ds_read_b32 is bank-conflict free;
+//   * weights are pre-packed in MFMA A-fragment order (icm_pack_weights) and stream straight from
+//     L2 into registers as one coalesced 16-B load per lane per (tap, 8-channel chunk, 32-co tile);
+//   * "scatter" forms (convT fwd / conv dgrad) run as stride^2 output-parity classes, each a dense
+//     stride-1 gather with its own tap subset -- no zero-stuffing, no atomics;
+//   * pointwise neighbours are fused: operand activation on the LDS staging path (virtual GELU,
+//     x^2 for GDN) and the epilogues listed in icm_hip.h (bias, residual, GDN rsqrt, GELU', LRP tanh,
+//     PixelShuffle store, gradient accumulation).
+#include <vector>
+#include "icm_common.h"
+
+namespace icm {
+
+#define ICM_MAX_TAPS 32
+#define ICM_MAX_GROUPS 3
+
+struct ConvPtrs {
+  const float* x;
+  const float* wp;
+  const float* bias;
+  float* y;
+  const float* res;
+  const float* aux;
+  const float* aux2;
+  float* y2;
+};
+
+struct ConvDesc {
+  ConvPtrs g[ICM_MAX_GROUPS];
+  long long x_bs, y_bs, res_bs, aux_bs, aux2_bs, y2_bs;
+  int N, Cin, H, W, Cout, OHf, OWf;
+  int OHv, OWv;
+  int out_sy, out_oy, out_sx, out_ox;
+  int iy0, ix0, S;
+  int ntaps;
+  int lgTW, lgTH, lgTI;
+  int PH, PW, PWh, PWrow, PP, CKS, lgPWp2;
+  FastDiv dTIPH, dPH;
+  int tiles_x, tiles_y, tiles_n;
+  int ncot, nchunks, ncb;
+  int pro_act, epi, accum, ps2;
+  short tapoff[ICM_MAX_TAPS];
+};
+
+template <int WCO, int WPX, int TCO, int TPX>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(WCO * WPX == 4, "4 waves per workgroup");
+  constexpr int BCO_T = WCO * TCO;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wco = wave / WPX, wpx = wave % WPX;
+  const int h = lane >> 5, l31 = lane & 31;
+  const ConvPtrs P = d.g[blockIdx.y];
+
+  int bid = blockIdx.x;
+  const int cb = bid % d.ncb;
+  int pt = bid / d.ncb;
+  const int tx_i = pt % d.tiles_x;
+  pt /= d.tiles_x;
+  const int ty_i = pt % d.tiles_y;
+  const int tn_i = pt / d.tiles_y;
+  const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
+  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+  const int rowmul = d.S * d.PWrow;
+
+  // LDS offset of this lane's pixel (per 32-pixel tile), including the k-parity plane h
+  int boff[TPX];
+#pragma unroll
+  for (int tp = 0; tp < TPX; ++tp) {
+    const int p = (wpx * TPX + tp) * 32 + l31;
+    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
+    boff[tp] = h * d.CKS + ti * d.PP + ty * rowmul + tx;
+  }
+
+  const int bufsz = 8 * d.CKS;
+  const int iyb = oy0 * d.S + d.iy0, ixb = ox0 * d.S + d.ix0;
+  const int PWp2m = (1 << d.lgPWp2) - 1;
+  const int total_e = (8 * (int)d.dTIPH.d) << d.lgPWp2;
+  const int HW = d.H * d.W;
+
+  auto stage = [&](int chunk, float* dst) {
+    for (int e = tid; e < total_e; e += 256) {
+      const int px = e & PWp2m;
+      const uint32_t r = (uint32_t)e >> d.lgPWp2;
+      if (px < d.PW) {
+        const uint32_t c8 = fdiv(r, d.dTIPH);
+        const uint32_t rem = r - c8 * d.dTIPH.d;
+        const uint32_t ti = fdiv(rem, d.dPH);
+        const uint32_t py = rem - ti * d.dPH.d;
+        const int c = chunk * 8 + (int)c8, n = n0 + (int)ti, iy = iyb + (int)py, ix = ixb + px;
+        float v = 0.0f;
+        if (c < d.Cin && n < d.N && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) {
+          v = P.x[(long long)n * d.x_bs + (long long)c * HW + iy * d.W + ix];
+          v = apply_act(v, d.pro_act);
+        }
+        const int col = (d.S == 2) ? ((px & 1) * d.PWh + (px >> 1)) : px;
+        dst[c8 * d.CKS + ti * d.PP + py * d.PWrow + col] = v;
+      }
+    }
+  };
+
+  f32x16 acc[TCO][TPX];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int b = 0; b < TPX; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const f32x4* wp4 = reinterpret_cast<const f32x4*>(P.wp);
+  const int cot0 = cb * BCO_T + wco * TCO;
+  int cot_ld[TCO];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a) cot_ld[a] = min(cot0 + a, d.ncot - 1);
+
+  stage(0, smem);
+  __syncthreads();
+  for (int chunk = 0; chunk < d.nchunks; ++chunk) {
+    const float* cur = smem + (chunk & 1) * bufsz;
+    if (chunk + 1 < d.nchunks) stage(chunk + 1, smem + ((chunk + 1) & 1) * bufsz);
+    const long long wbase = (long long)chunk * d.ntaps * d.ncot;
+    f32x4 a_nxt[TCO];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(wbase + cot_ld[a]) * 64 + lane];
+    for (int t = 0; t < d.ntaps; ++t) {
+      f32x4 a_cur[TCO];
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
+      if (t + 1 < d.ntaps) {
+#pragma unroll
+        for (int a = 0; a < TCO; ++a)
+          a_nxt[a] = wp4[(wbase + (long long)(t + 1) * d.ncot + cot_ld[a]) * 64 + lane];
+      }
+      const int toff = d.tapoff[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bv[TPX];
+#pragma unroll
+        for (int tp = 0; tp < TPX; ++tp) bv[tp] = cur[boff[tp] + toff + 2 * j * d.CKS];
+#pragma unroll
+        for (int a = 0; a < TCO; ++a)
+#pragma unroll
+          for (int tp = 0; tp < TPX; ++tp)
+            acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[tp], acc[a][tp], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h
+  const long long plane = (long long)d.OHf * d.OWf;
+#pragma unroll
+  for (int tp = 0; tp < TPX; ++tp) {
+    const int p = (wpx * TPX + tp) * 32 + l31;
+    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
+    const int n = n0 + ti, oyv = oy0 + ty, oxv = ox0 + tx;
+    const bool pvalid = (n < d.N) && (oyv < d.OHv) && (oxv < d.OWv);
+    const int oy = oyv * d.out_sy + d.out_oy, ox = oxv * d.out_sx + d.out_ox;
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+      const int cot = cot0 + a;
+      if (cot >= d.ncot) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (!pvalid || co >= d.Cout) continue;
+        long long pix;
+        if (d.ps2) {
+          pix = (long long)(co >> 2) * plane + (long long)(oy * 2 + ((co >> 1) & 1)) * d.OWf + ox * 2 + (co & 1);
+        } else {
+          pix = (long long)co * plane + (long long)oy * d.OWf + ox;
+        }
+        float v = acc[a][tp][r];
+        if (P.bias) v += P.bias[co];
+        switch (d.epi) {
+          case ICM_EPI_RES: v += P.res[n * d.res_bs + pix]; break;
+          case ICM_EPI_RES_GELU: v += gelu_f(P.res[n * d.res_bs + pix]); break;
+          case ICM_EPI_GDN: {
+            if (P.y2) P.y2[n * d.y2_bs + pix] = v;
+            v = P.aux[n * d.aux_bs + pix] * rsqrtf(v);
+          } break;
+          case ICM_EPI_IGDN: {
+            if (P.y2) P.y2[n * d.y2_bs + pix] = v;
+            v = P.aux[n * d.aux_bs + pix] * sqrtf(v);
+          } break;
+          case ICM_EPI_MUL_DGELU: v *= dgelu_f(P.aux[n * d.aux_bs + pix]); break;
+          case ICM_EPI_AXPY2: v = P.aux2[n * d.aux2_bs + pix] + 2.0f * P.aux[n * d.aux_bs + pix] * v; break;
+          case ICM_EPI_LRP: {
+            const float t = tanhf(v);
+            if (P.y2) P.y2[n * d.y2_bs + pix] = t;
+            v = P.aux[n * d.aux_bs + pix] + 0.5f * t;
+          } break;
+          default: break;
+        }
+        float* yp = P.y + n * d.y_bs + pix;
+        if (d.accum) v += *yp;
+        *yp = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: wp[((chunk*ntaps + t)*ncot + cot)*64 + lane][j] = W[co = cot*32 + (lane&31)]
+//                                                                    [ci = chunk*8 + 2*j + (lane>>5)][tap t]
+struct PackDesc {
+  const float* w;
+  float* wp;
+  int Co, Ci, KHW, src_out_major, ntaps, ncot, nchunks, nonneg;
+  float bound, pedestal;
+  short tapidx[ICM_MAX_TAPS];
+};
+
+__global__ void pack_weights_kernel(const PackDesc d) {
+  const long long total = (long long)d.nchunks * d.ntaps * d.ncot * 256;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long long q = i >> 8;
+    const int cot = (int)(q % d.ncot);
+    q /= d.ncot;
+    const int t = (int)(q % d.ntaps);
+    const int chunk = (int)(q / d.ntaps);
+    const int co = cot * 32 + (lane & 31), ci = chunk * 8 + 2 * j + (lane >> 5);
+    float v = 0.0f;
+    if (co < d.Co && ci < d.Ci) {
+      const long long src = d.src_out_major ? ((long long)co * d.Ci + ci) : ((long long)ci * d.Co + co);
+      v = d.w[src * d.KHW + d.tapidx[t]];
+      if (d.nonneg) {
+        v = fmaxf(v, d.bound);
+        v = v * v - d.pedestal;
+      }
+    }
+    d.wp[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------- host planning
+struct Tap {
+  int kidx;    // kh*KW + kw in the canonical weight
+  int dy, dx;  // patch-relative offsets
+};
+struct ConvClass {
+  int cy, cx;      // output parity (scatter) -- 0,0 for gather
+  int iy0, ix0;    // input coordinate of patch row/col 0 for virtual output 0
+  int ey, ex;      // patch extents contributed by taps (max dy + 1)
+  std::vector<Tap> taps;
+};
+
+// Taps of one axis for output parity c of a scatter conv: k with (c + pad - k) % s == 0, input offset (c+pad-k)/s
+static void axis_taps(int K, int s, int pad, int c, std::vector<int>& ks, std::vector<int>& dis) {
+  for (int k = 0; k < K; ++k) {
+    const int v = c + pad - k;
+    if (((v % s) + s) % s != 0) continue;
+    ks.push_back(k);
+    dis.push_back(v >= 0 ? v / s : -((-v) / s));
+  }
+}
+
+static std::vector<ConvClass> build_classes(int KH, int KW, int stride, int pad, int transposed) {
+  std::vector<ConvClass> out;
+  if (!transposed) {
+    ConvClass c;
+    c.cy = c.cx = 0;
+    c.iy0 = c.ix0 = -pad;
+    c.ey = KH;
+    c.ex = KW;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) c.taps.push_back({kh * KW + kw, kh, kw});
+    out.push_back(c);
+    return out;
+  }
+  for (int cy = 0; cy < stride; ++cy)
+    for (int cx = 0; cx < stride; ++cx) {
+      std::vector<int> khs, dys, kws, dxs;
+      axis_taps(KH, stride, pad, cy, khs, dys);
+      axis_taps(KW, stride, pad, cx, kws, dxs);
+      ConvClass c;
+      c.cy = cy;
+      c.cx = cx;
+      int miny = 0, minx = 0, maxy = 0, maxx = 0;
+      for (size_t i = 0; i < dys.size(); ++i) {
+        miny = i ? std::min(miny, dys[i]) : dys[i];
+        maxy = i ? std::max(maxy, dys[i]) : dys[i];
+      }
+      for (size_t i = 0; i < dxs.size(); ++i) {
+        minx = i ? std::min(minx, dxs[i]) : dxs[i];
+        maxx = i ? std::max(maxx, dxs[i]) : dxs[i];
+      }
+      c.iy0 = miny;
+      c.ix0 = minx;
+      c.ey = maxy - miny + 1;
+      c.ex = maxx - minx + 1;
+      for (size_t a = 0; a < khs.size(); ++a)
+        for (size_t b = 0; b < kws.size(); ++b)
+          c.taps.push_back({khs[a] * KW + kws[b], dys[a] - miny, dxs[b] - minx});
+      out.push_back(c);
+    }
+  return out;
+}
+
+struct KernelCfg {
+  int wco, wpx, tco, tpx;
+  void (*fn)(const ConvDesc);
+};
+static const KernelCfg kCfgs[] = {
+    {1, 4, 2, 2, conv_igemm_kernel<1, 4, 2, 2>},  // 64 x 256
+    {1, 4, 3, 1, conv_igemm_kernel<1, 4, 3, 1>},  // 96 x 128
+    {1, 4, 5, 1, conv_igemm_kernel<1, 4, 5, 1>},  // 160 x 128
+    {1, 4, 1, 2, conv_igemm_kernel<1, 4, 1, 2>},  // 32 x 256
+    {2, 2, 2, 1, conv_igemm_kernel<2, 2, 2, 1>},  // 128 x 64
+    {2, 2, 1, 1, conv_igemm_kernel<2, 2, 1, 1>},  // 64 x 64
+    {4, 1, 1, 1, conv_igemm_kernel<4, 1, 1, 1>},  // 128 x 32
+    {1, 4, 1, 1, conv_igemm_kernel<1, 4, 1, 1>},  // 32 x 128
+};
+static int g_force_cfg = -1;
+
+struct Geometry {
+  int lgTW, lgTH, lgTI, PH, PW, PWh, PWrow, PP, CKS, tiles_x, tiles_y, tiles_n;
+  size_t lds_bytes;
+};
+
+static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, int ex) {
+  Geometry g;
+  const int lgB = ceil_log2(bpx);
+  g.lgTW = std::min(std::min(5, lgB), ceil_log2(OWv));
+  g.lgTH = std::min(lgB - g.lgTW, ceil_log2(OHv));
+  g.lgTI = lgB - g.lgTW - g.lgTH;
+  const int TW = 1 << g.lgTW, TH = 1 << g.lgTH, TI = 1 << g.lgTI;
+  g.PW = (TW - 1) * S + ex;
+  g.PH = (TH - 1) * S + ey;
+  g.PWh = (g.PW + 1) / 2;
+  g.PWrow = (S == 2) ? 2 * g.PWh : g.PW;
+  g.PP = g.PH * g.PWrow;
+  g.CKS = TI * g.PP;
+  g.tiles_x = cdiv(OWv, TW);
+  g.tiles_y = cdiv(OHv, TH);
+  g.tiles_n = cdiv(N, TI);
+  g.lds_bytes = (size_t)2 * 8 * g.CKS * sizeof(float);
+  return g;
+}
+
+static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls, long long wp_off, int S_in,
+                     int out_s, hipStream_t stream) {
+  const icm_conv_args& a = arr[0];
+  const int OHv = a.transposed ? cdiv(a.OH - cls.cy, out_s) : a.OH;
+  const int OWv = a.transposed ? cdiv(a.OW - cls.cx, out_s) : a.OW;
+  if (OHv <= 0 || OWv <= 0) return ICM_OK;
+  const int ncot = cdiv(a.Cout, 32), nchunks = cdiv(a.Cin, 8);
+  const int ntaps = (int)cls.taps.size();
+  if (ntaps > ICM_MAX_TAPS) return ICM_ERR_UNSUPPORTED;
+
+  // pick the tile configuration: minimise (waves of workgroups) x (MFMA work per workgroup)
+  int best = -1;
+  double best_cost = 1e300;
+  Geometry bg{};
+  const int ncfg = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+  for (int i = 0; i < ncfg; ++i) {
+    if (g_force_cfg >= 0 && i != g_force_cfg) continue;
+    const KernelCfg& c = kCfgs[i];
+    const int bpx = c.wpx * c.tpx * 32, bco_t = c.wco * c.tco;
+    Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex);
+    if (g.lds_bytes > 64 * 1024 && g_force_cfg < 0) {
+      if (g.lds_bytes > 160 * 1024) continue;
+    }
+    if (g.lds_bytes > 160 * 1024) continue;
+    const long long blocks = (long long)cdiv(ncot, bco_t) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
+    const int acc_regs = c.tco * c.tpx * 16;
+    int occ = acc_regs <= 48 ? 3 : (acc_regs <= 96 ? 2 : 1);
+    occ = std::min<long long>(occ, std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(g.lds_bytes, 1)));
+    const double rounds = (double)cdiv((int)std::min<long long>(blocks, 1 << 30), 256 * occ);
+    // per-workgroup time ~ MFMAs per wave (64 cycles each), inflated when a wave has little register reuse
+    const double mfma = (double)c.tco * c.tpx * nchunks * ntaps * 4;
+    const double reuse_pen = 1.0 + 0.35 / (c.tco * c.tpx);
+    const double cost = rounds * occ * mfma * reuse_pen + rounds * 200.0;
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = i;
+      bg = g;
+    }
+  }
+  if (best < 0) return ICM_ERR_UNSUPPORTED;
+  const KernelCfg& c = kCfgs[best];
+
+  ConvDesc d;
+  for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
+    const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
+    d.g[gi].x = s.x;
+    d.g[gi].wp = s.wp + wp_off;
+    d.g[gi].bias = s.bias;
+    d.g[gi].y = s.y;
+    d.g[gi].res = s.res;
+    d.g[gi].aux = s.aux;
+    d.g[gi].aux2 = s.aux2;
+    d.g[gi].y2 = s.y2;
+  }
+  d.x_bs = a.x_bs; d.y_bs = a.y_bs; d.res_bs = a.res_bs; d.aux_bs = a.aux_bs; d.aux2_bs = a.aux2_bs; d.y2_bs = a.y2_bs;
+  d.N = a.N; d.Cin = a.Cin; d.H = a.H; d.W = a.W; d.Cout = a.Cout;
+  d.ps2 = a.pixel_shuffle == 2;
+  d.OHf = d.ps2 ? a.OH * 2 : a.OH;
+  d.OWf = d.ps2 ? a.OW * 2 : a.OW;
+  d.OHv = OHv; d.OWv = OWv;
+  d.out_sy = d.out_sx = out_s;
+  d.out_oy = cls.cy; d.out_ox = cls.cx;
+  d.iy0 = cls.iy0; d.ix0 = cls.ix0; d.S = S_in;
+  d.ntaps = ntaps;
+  d.lgTW = bg.lgTW; d.lgTH = bg.lgTH; d.lgTI = bg.lgTI;
+  d.PH = bg.PH; d.PW = bg.PW; d.PWh = bg.PWh; d.PWrow = bg.PWrow; d.PP = bg.PP; d.CKS = bg.CKS;
+  d.lgPWp2 = ceil_log2(bg.PW);
+  d.dTIPH = make_fastdiv((uint32_t)((1 << bg.lgTI) * bg.PH));
+  d.dPH = make_fastdiv((uint32_t)bg.PH);
+  d.tiles_x = bg.tiles_x; d.tiles_y = bg.tiles_y; d.tiles_n = bg.tiles_n;
+  d.ncot = ncot; d.nchunks = nchunks; d.ncb = cdiv(ncot, c.wco * c.tco);
+  d.pro_act = a.pro_act; d.epi = a.epi; d.accum = a.accum;
+  for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapoff[t] = 0;
+  for (int t = 0; t < ntaps; ++t) {
+    const Tap& tp = cls.taps[t];
+    const int col = (S_in == 2) ? ((tp.dx & 1) * bg.PWh + (tp.dx >> 1)) : tp.dx;
+    d.tapoff[t] = (short)(tp.dy * bg.PWrow + col);
+  }
+  const long long nblk = (long long)d.ncb * d.tiles_x * d.tiles_y * d.tiles_n;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
+  if (bg.lds_bytes > 64 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)bg.lds_bytes);
+  }
+  hipLaunchKernelGGL(c.fn, dim3((unsigned)nblk, ngroups, 1), dim3(256), bg.lds_bytes, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+static int validate(const icm_conv_args& a) {
+  if (!a.x || !a.wp || !a.y) return ICM_ERR_ARG;
+  if (a.N <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.H <= 0 || a.W <= 0 || a.OH <= 0 || a.OW <= 0) return ICM_ERR_ARG;
+  if (a.KH <= 0 || a.KW <= 0 || a.KH * a.KW > ICM_MAX_TAPS) return ICM_ERR_UNSUPPORTED;
+  if (a.stride != 1 && a.stride != 2) return ICM_ERR_UNSUPPORTED;
+  if (!a.transposed) {
+    if (a.OH != (a.H + 2 * a.pad - a.KH) / a.stride + 1 || a.OW != (a.W + 2 * a.pad - a.KW) / a.stride + 1)
+      return ICM_ERR_ARG;
+  }
+  if ((a.epi == ICM_EPI_RES || a.epi == ICM_EPI_RES_GELU) && !a.res) return ICM_ERR_ARG;
+  if ((a.epi == ICM_EPI_GDN || a.epi == ICM_EPI_IGDN || a.epi == ICM_EPI_MUL_DGELU || a.epi == ICM_EPI_LRP ||
+       a.epi == ICM_EPI_AXPY2) && !a.aux)
+    return ICM_ERR_ARG;
+  if (a.epi == ICM_EPI_AXPY2 && !a.aux2) return ICM_ERR_ARG;
+  if (a.pixel_shuffle != 0 && a.pixel_shuffle != 2) return ICM_ERR_UNSUPPORTED;
+  if (a.pixel_shuffle == 2 && (a.Cout % 4 != 0 || a.transposed)) return ICM_ERR_ARG;
+  return ICM_OK;
+}
+
+static int conv_run_grouped(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
+  if (!arr || ngroups < 1 || ngroups > ICM_MAX_GROUPS) return ICM_ERR_ARG;
+  for (int i = 0; i < ngroups; ++i) {
+    int rc = validate(arr[i]);
+    if (rc) return rc;
+  }
+  const icm_conv_args& a = arr[0];
+  std::vector<ConvClass> classes = build_classes(a.KH, a.KW, a.stride, a.pad, a.transposed);
+  const int ncot = cdiv(a.Cout, 32), nchunks = cdiv(a.Cin, 8);
+  long long off = 0;
+  for (const ConvClass& cls : classes) {
+    int rc = run_class(arr, ngroups, cls, off, a.transposed ? 1 : a.stride, a.transposed ? a.stride : 1, stream);
+    if (rc) return rc;
+    off += (long long)nchunks * (long long)cls.taps.size() * ncot * 256;
+  }
+  return ICM_OK;
+}
+
+}  // namespace icm
+
+extern "C" {
+
+int icm_conv_run(const icm_conv_args* a, void* stream) {
+  return icm::conv_run_grouped(a, 1, (hipStream_t)stream);
+}
+int icm_conv_run_grouped(const icm_conv_args* a, int ngroups, void* stream) {
+  return icm::conv_run_grouped(a, ngroups, (hipStream_t)stream);
+}
+int icm_conv2d_fwd(const icm_conv_args* a, void* stream) {
+  if (!a || a->transposed) return ICM_ERR_ARG;
+  return icm_conv_run(a, stream);
+}
+int icm_convT2d_dgrad(const icm_conv_args* a, void* stream) {
+  if (!a || a->transposed) return ICM_ERR_ARG;
+  return icm_conv_run(a, stream);
+}
+int icm_conv2d_dgrad(const icm_conv_args* a, void* stream) {
+  if (!a || !a->transposed) return ICM_ERR_ARG;
+  return icm_conv_run(a, stream);
+}
+int icm_convT2d_fwd(const icm_conv_args* a, void* stream) {
+  if (!a || !a->transposed) return ICM_ERR_ARG;
+  return icm_conv_run(a, stream);
+}
+
+void icm_debug_force_conv_cfg(int idx) { icm::g_force_cfg = idx; }
+
+int64_t icm_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
+  return (int64_t)icm::cdiv(Cin, 8) * KH * KW * icm::cdiv(Cout, 32) * 256;
+}
+
+int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int src_out_major,
+                     int transposed, int stride, int pad, int nonneg, float bound, float pedestal, void* stream) {
+  using namespace icm;
+  if (!w || !wp || Cout <= 0 || Cin <= 0 || KH * KW > ICM_MAX_TAPS || (stride != 1 && stride != 2)) return ICM_ERR_ARG;
+  std::vector<ConvClass> classes = build_classes(KH, KW, stride, pad, transposed);
+  const int ncot = cdiv(Cout, 32), nchunks = cdiv(Cin, 8);
+  long long off = 0;
+  for (const ConvClass& cls : classes) {
+    const int ntaps = (int)cls.taps.size();
+    if (ntaps == 0) continue;
+    PackDesc d;
+    d.w = w;
+    d.wp = wp + off;
+    d.Co = Cout; d.Ci = Cin; d.KHW = KH * KW; d.src_out_major = src_out_major;
+    d.ntaps = ntaps; d.ncot = ncot; d.nchunks = nchunks; d.nonneg = nonneg;
+    d.bound = bound; d.pedestal = pedestal;
+    for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
+    for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
+    const long long total = (long long)nchunks * ntaps * ncot * 256;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
+    ICM_CHECK_LAUNCH();
+    off += total;
+  }
+  return ICM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+// HBM-bound pointwise / reduction kernels of the WACNN hot path (gfx950).
+// All are grid-stride, 16-B vectorised where the layout allows, one pass over their operands.
+#include <algorithm>
+#include "icm_common.h"
+
+namespace icm {
+
+static inline int grid_for(long long n, int per_thread = 4) {
+  long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+  return (int)std::max<long long>(1, std::min<long long>(b, 256 * 8));
+}
+
+#define GRID_STRIDE(i, n) \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- channel sum: out[c] = sum_{n,p} x[n,c,p]
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long long bs, int N, int C,
+                                                          int HW, float* __restrict__ out, int accum) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float s = 0.0f;
+  const long long total = (long long)N * HW;
+  for (long long i = threadIdx.x; i < total; i += 256) {
+    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+    s += x[n * bs + (long long)c * HW + p];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = red[0] + red[1] + red[2] + red[3];
+    if (accum) t += out[c];
+    out[c] = t;
+  }
+}
+
+// ---------------------------------------------------------------- NonNegativeParametrizer
+__global__ void nonneg_fwd_kernel(const float* p, float* out, long long n, float bound, float ped) {
+  GRID_STRIDE(i, n) {
+    const float v = fmaxf(p[i], bound);
+    out[i] = v * v - ped;
+  }
+}
+__global__ void nonneg_bwd_kernel(const float* p, const float* g, float* dp, long long n, float bound, int accum) {
+  GRID_STRIDE(i, n) {
+    const float pv = p[i];
+    const float gg = g[i] * 2.0f * fmaxf(pv, bound);
+    float r = (pv >= bound || gg < 0.0f) ? gg : 0.0f;
+    if (accum) r += dp[i];
+    dp[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------- GDN backward pre-pass
+__global__ void gdn_bwd_pre_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                   const float* __restrict__ nrm, float* __restrict__ dn, float* __restrict__ t1,
+                                   long long n, int inverse) {
+  GRID_STRIDE(i, n) {
+    const float nv = nrm[i], gv = g[i], xv = x[i];
+    if (inverse) {
+      const float s = sqrtf(nv);
+      t1[i] = gv * s;
+      dn[i] = 0.5f * gv * xv / s;
+    } else {
+      const float r = rsqrtf(nv);
+      t1[i] = gv * r;
+      dn[i] = -0.5f * gv * xv * r / nv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GELU / gate / grad plumbing
+__global__ void gelu_fwd_kernel(const float* x, float* y, long long n) {
+  GRID_STRIDE(i, n) y[i] = gelu_f(x[i]);
+}
+__global__ void gate_fwd_kernel(const float* a_pre, const float* b, const float* x, float* out, long long n) {
+  GRID_STRIDE(i, n) out[i] = gelu_f(a_pre[i]) * sigmoid_f(b[i]) + x[i];
+}
+__global__ void gate_bwd_kernel(const float* g, const float* a_pre, const float* b, float* da, float* db, float* dx,
+                                long long n, int accum_da, int accum_dx) {
+  GRID_STRIDE(i, n) {
+    const float gv = g[i], ap = a_pre[i], s = sigmoid_f(b[i]);
+    float va = gv * s * dgelu_f(ap);
+    if (accum_da) va += da[i];
+    da[i] = va;
+    db[i] = gv * gelu_f(ap) * s * (1.0f - s);
+    float vx = gv;
+    if (accum_dx) vx += dx[i];
+    dx[i] = vx;
+  }
+}
+__global__ void add_grad_kernel(const float* src, const float* pre, float* dst, long long n, int accum) {
+  GRID_STRIDE(i, n) {
+    float v = src[i];
+    if (pre) v *= dgelu_f(pre[i]);
+    if (accum) v += dst[i];
+    dst[i] = v;
+  }
+}
+__global__ void ste_round_offset_kernel(const float* z, const float* quant, float* zh, int N, int C, int HW) {
+  const long long n = (long long)N * C * HW;
+  GRID_STRIDE(i, n) {
+    const int c = (int)((i / HW) % C);
+    const float med = quant[c * 3 + 1];
+    const float t = z[i] - med;
+    zh[i] = ((rintf(t) - t) + t) + med;
+  }
+}
+__global__ void copy_strided_kernel(const float* src, long long sbs, float* dst, long long dbs, int N, int C, int HW,
+                                    int accum) {
+  const long long per = (long long)C * HW, n = (long long)N * per;
+  GRID_STRIDE(i, n) {
+    const long long b = i / per, r = i - b * per;
+    float v = src[b * sbs + r];
+    if (accum) v += dst[b * dbs + r];
+    dst[b * dbs + r] = v;
+  }
+}
+// dpre[n,c,p] = g[n,c,p] * 0.5 * (1 - t^2)   (LRP tail backward, cnn.py:177-178)
+__global__ void lrp_bwd_kernel(const float* g, long long gbs, const float* t, long long tbs, float* dpre, long long dbs,
+                               int N, int C, int HW) {
+  const long long per = (long long)C * HW, n = (long long)N * per;
+  GRID_STRIDE(i, n) {
+    const long long b = i / per, r = i - b * per;
+    const float tv = t[b * tbs + r];
+    dpre[b * dbs + r] = g[b * gbs + r] * 0.5f * (1.0f - tv * tv);
+  }
+}
+// dst[n][c*4 + dy*2 + dx][y][x] = src[n][c][2y+dy][2x+dx]   (inverse of nn.PixelShuffle(2))
+__global__ void pixel_unshuffle2_kernel(const float* src, float* dst, int N, int C, int H, int W) {
+  const long long n = (long long)N * C * 4 * H * W;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % W);
+    long long q = i / W;
+    const int y = (int)(q % H); q /= H;
+    const int c4 = (int)(q % (C * 4));
+    const int b = (int)(q / (C * 4));
+    const int c = c4 >> 2, dy = (c4 >> 1) & 1, dx = c4 & 1;
+    dst[i] = src[(((long long)b * C + c) * (2 * H) + 2 * y + dy) * (2 * W) + 2 * x + dx];
+  }
+}
+__global__ void fill_kernel(float* p, long long n, float v) {
+  GRID_STRIDE(i, n) p[i] = v;
+}
+
+// ---------------------------------------------------------------- R-D loss
+__device__ __forceinline__ void block_atomic_add(float v, float* dst, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void rd_reduce_kernel(const float* x, const float* xh, long long nx, const float* ly,
+                                                        long long ny, const float* lz, long long nz, float* out) {
+  __shared__ float red[4];
+  float se = 0.0f, sy = 0.0f, sz = 0.0f;
+  GRID_STRIDE(i, nx) {
+    const float d = xh[i] - x[i];
+    se += d * d;
+  }
+  GRID_STRIDE(i, ny) sy += logf(ly[i]);
+  GRID_STRIDE(i, nz) sz += logf(lz[i]);
+  block_atomic_add(se, out + 1, red);
+  block_atomic_add(sy, out + 3, red);
+  block_atomic_add(sz, out + 4, red);
+}
+__global__ void rd_finish_kernel(float* out, long long nx, long long npix, float lmbda) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float mse = out[1] / (float)nx;
+    const float denom = -0.69314718055994530942f * (float)npix;
+    const float bpp = out[3] / denom + out[4] / denom;
+    out[0] = bpp;
+    out[1] = mse;
+    out[2] = lmbda * 65025.0f * mse + bpp;
+  }
+}
+__global__ void rd_bwd_kernel(const float* x, const float* xh, long long nx, const float* ly, long long ny,
+                              const float* lz, long long nz, long long npix, float lmbda, float gscale, float* dxh,
+                              float* dly, float* dlz) {
+  const float cm = gscale * lmbda * 65025.0f * 2.0f / (float)nx;
+  const float cl = gscale / (-0.69314718055994530942f * (float)npix);
+  GRID_STRIDE(i, nx) dxh[i] = cm * (xh[i] - x[i]);
+  GRID_STRIDE(i, ny) dly[i] = cl / ly[i];
+  GRID_STRIDE(i, nz) dlz[i] = cl / lz[i];
+}
+
+// ---------------------------------------------------------------- optimiser
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.0f;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  const long long n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? n / 4 : 0;
+  GRID_STRIDE(i, n4) {
+    const f32x4 v = g4[i];
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    s += g[i] * g[i];
+  block_atomic_add(s, out, red);
+}
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, const float* sqnorm, float max_norm, float gscale) {
+  float coef = gscale;
+  if (sqnorm) {
+    const float total = sqrtf(*sqnorm) * gscale;
+    coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+  }
+  const float step_size = lr / bc1;
+  GRID_STRIDE(i, n) {
+    const float gv = g[i] * coef;
+    const float mv = b1 * m[i] + (1.0f - b1) * gv;
+    const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mv / denom);
+  }
+}
+
+}  // namespace icm
+
+using namespace icm;
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, void* stream) {
+  if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, ST, x, (long long)x_bs, N, C, HW, out, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_nonneg_fwd(const float* p, float* out, int64_t n, float bound, float pedestal, void* stream) {
+  if (!p || !out || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(nonneg_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, out, (long long)n, bound, pedestal);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_nonneg_bwd(const float* p, const float* g_eff, float* dp, int64_t n, float bound, int accum, void* stream) {
+  if (!p || !g_eff || !dp || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(nonneg_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g_eff, dp, (long long)n, bound, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gdn_bwd_pre(const float* g, const float* x, const float* nrm, float* dn, float* t1, int64_t n, int inverse,
+                    void* stream) {
+  if (!g || !x || !nrm || !dn || !t1 || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gdn_bwd_pre_kernel, dim3(grid_for(n)), dim3(256), 0, ST, g, x, nrm, dn, t1, (long long)n, inverse);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, x, y, (long long)n);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gate_fwd(const float* a_pre, const float* b, const float* x, float* out, int64_t n, void* stream) {
+  if (!a_pre || !b || !x || !out || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, a_pre, b, x, out, (long long)n);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gate_bwd(const float* g, const float* a_pre, const float* b, float* da_pre, float* db, float* dx, int64_t n,
+                 int accum_da, int accum_dx, void* stream) {
+  if (!g || !a_pre || !b || !da_pre || !db || !dx || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, g, a_pre, b, da_pre, db, dx, (long long)n,
+                     accum_da, accum_dx);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_add_grad(const float* src, const float* mul_dgelu_of, float* dst, int64_t n, int accum, void* stream) {
+  if (!src || !dst || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(add_grad_kernel, dim3(grid_for(n)), dim3(256), 0, ST, src, mul_dgelu_of, dst, (long long)n, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_ste_round_offset(const float* z, const float* quantiles, float* z_hat, int N, int C, int HW, void* stream) {
+  if (!z || !quantiles || !z_hat || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(ste_round_offset_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ST, z, quantiles,
+                     z_hat, N, C, HW);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int N, int C, int HW, int accum,
+                     void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ST, src,
+                     (long long)src_bs, dst, (long long)dst_bs, N, C, HW, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_lrp_bwd(const float* g, int64_t g_bs, const float* t, int64_t t_bs, float* dpre, int64_t d_bs, int N, int C,
+                int HW, void* stream) {
+  if (!g || !t || !dpre || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(lrp_bwd_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ST, g, (long long)g_bs, t,
+                     (long long)t_bs, dpre, (long long)d_bs, N, C, HW);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int W, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for((long long)N * C * 4 * H * W)), dim3(256), 0, ST, src, dst,
+                     N, C, H, W);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_fill(float* p, int64_t n, float v, void* stream) {
+  if (!p || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, (long long)n, v);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_rd_loss_fwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
+                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, void* stream) {
+  if (!x || !x_hat || !lik_y || !lik_z || !out || n_img_elems <= 0 || num_pixels <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(rd_reduce_kernel, dim3(grid_for(n_img_elems, 8)), dim3(256), 0, ST, x, x_hat,
+                     (long long)n_img_elems, lik_y, (long long)n_y, lik_z, (long long)n_z, out);
+  ICM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rd_finish_kernel, dim3(1), dim3(64), 0, ST, out, (long long)n_img_elems, (long long)num_pixels,
+                     lmbda);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_rd_loss_bwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
+                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float gscale, float* dx_hat,
+                    float* dlik_y, float* dlik_z, void* stream) {
+  if (!x || !x_hat || !lik_y || !lik_z || !dx_hat || !dlik_y || !dlik_z) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(rd_bwd_kernel, dim3(grid_for(n_img_elems)), dim3(256), 0, ST, x, x_hat, (long long)n_img_elems,
+                     lik_y, (long long)n_y, lik_z, (long long)n_z, (long long)num_pixels, lmbda, gscale, dx_hat, dlik_y,
+                     dlik_z);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
+  if (!g || !out || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 16)), dim3(256), 0, ST, g, (long long)n, out);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return ICM_ERR_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
+                     bc1, bc2s, sqnorm, max_norm, gscale);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+const char* icm_strerror(int code) {
+  switch (code) {
+    case ICM_OK: return "ok";
+    case ICM_ERR_ARG: return "invalid argument";
+    case ICM_ERR_LAUNCH: return "kernel launch failed";
+    case ICM_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+int icm_version(void) { return 1; }
+
+}  // extern "C"

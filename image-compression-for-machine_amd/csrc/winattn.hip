@@ -1,0 +1,328 @@
+// Window multi-head self-attention core (forward + backward) on NCHW tensors, gfx950.
+//
+// Replaces WinBasedAttention / WindowAttention between the qkv and proj Linears
+// (layers/win_attention.py:84-115,153-207).  The reference materialises six permuted copies
+// (NCHW->NHWC, roll, window_partition, qkv reshape/permute, window_reverse, roll back, NHWC->NCHW);
+// here the cyclic shift, window partition, head split, relative-position-bias gather and the 0/-100
+// shift mask are pure address arithmetic on the NCHW qkv tensor produced by the 1x1-conv GEMM.
+//
+// One workgroup = one window of one image; each wave walks heads.  Lane = query token.  K and V of the
+// head live in LDS (broadcast reads), the score row lives in a per-wave LDS matrix with odd row stride
+// (conflict-free row and column sweeps), so the backward pass gets P^T / dS^T for dV, dK without any
+// cross-lane shuffles.  Relative-position-bias gradients are reduced per wave in LDS (all lanes of one
+// instruction hit distinct table entries) and flushed with one atomicAdd per table entry per workgroup.
+// TODO(next round): QK^T / PV on v_mfma_f32_16x16x4_f32; they are 0.6 % of the model FLOPs.
+#include <algorithm>
+#include "icm_common.h"
+
+namespace icm {
+
+struct WaDesc {
+  const float* qkv;
+  const float* table;
+  float* out;          // fwd
+  const float* dout;   // bwd
+  float* dqkv;         // bwd
+  float* dtable;       // bwd
+  int N, C, H, W, heads, ws, shift, hd, T, nwx, nwy;
+  float scale;
+};
+
+__device__ __forceinline__ int region(int s, int L, int ws, int shift) {
+  return s < L - ws ? 0 : (s < L - shift ? 1 : 2);
+}
+
+// Common per-token geometry
+struct Tok {
+  int pix;   // oy*W + ox in the original (un-shifted) image
+  int lab;   // shift-mask region label
+  int r, c;  // row / col inside the window
+};
+__device__ __forceinline__ Tok token(const WaDesc& d, int wy, int wx, int j) {
+  Tok t;
+  t.r = j / d.ws;
+  t.c = j - t.r * d.ws;
+  const int sy = wy * d.ws + t.r, sx = wx * d.ws + t.c;
+  int oy = sy + d.shift, ox = sx + d.shift;
+  if (oy >= d.H) oy -= d.H;
+  if (ox >= d.W) ox -= d.W;
+  t.pix = oy * d.W + ox;
+  t.lab = d.shift > 0 ? region(sy, d.H, d.ws, d.shift) * 3 + region(sx, d.W, d.ws, d.shift) : 0;
+  return t;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int T = d.T, TS = T + 1;
+  float* Ksh = smem + wave * (2 * T * HD + T * TS);
+  float* Vsh = Ksh + T * HD;
+  float* Ssh = Vsh + T * HD;
+  int bid = blockIdx.x;
+  const int wx = bid % d.nwx; bid /= d.nwx;
+  const int wy = bid % d.nwy;
+  const int n = bid / d.nwy;
+  const long long HW = (long long)d.H * d.W;
+  const float* base = d.qkv + (long long)n * 3 * d.C * HW;
+  const bool active = lane < T;
+  const Tok me = token(d, wy, wx, active ? lane : 0);
+  const int tw = 2 * d.ws - 1;
+
+  for (int head = wave; head < d.heads; head += nwaves) {
+    const float* qp = base + (long long)(head * HD) * HW;
+    const float* kp = base + (long long)(d.C + head * HD) * HW;
+    const float* vp = base + (long long)(2 * d.C + head * HD) * HW;
+    float q[HD];
+    if (active) {
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) {
+        q[dd] = qp[dd * HW + me.pix] * d.scale;
+        Ksh[lane * HD + dd] = kp[dd * HW + me.pix];
+        Vsh[lane * HD + dd] = vp[dd * HW + me.pix];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    float m = -3.0e38f;
+    if (active) {
+      for (int j = 0; j < T; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) s += q[dd] * Ksh[j * HD + dd];
+        const Tok tj = token(d, wy, wx, j);
+        const int idx = (me.r - tj.r + d.ws - 1) * tw + (me.c - tj.c + d.ws - 1);
+        s += d.table[idx * d.heads + head];
+        if (d.shift > 0 && tj.lab != me.lab) s += -100.0f;
+        Ssh[lane * TS + j] = s;
+        m = fmaxf(m, s);
+      }
+      float l = 0.0f;
+      for (int j = 0; j < T; ++j) {
+        const float p = expf(Ssh[lane * TS + j] - m);
+        Ssh[lane * TS + j] = p;
+        l += p;
+      }
+      const float inv = 1.0f / l;
+      float o[HD];
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) o[dd] = 0.0f;
+      for (int j = 0; j < T; ++j) {
+        const float p = Ssh[lane * TS + j] * inv;
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) o[dd] += p * Vsh[j * HD + dd];
+      }
+      float* op = d.out + ((long long)n * d.C + head * HD) * HW;
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) op[dd * HW + me.pix] = o[dd];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int T = d.T, TS = T + 1;
+  const int tw = 2 * d.ws - 1, ntab = tw * tw;
+  const int per_wave = 4 * T * HD + T * TS + ntab;
+  float* Ksh = smem + wave * per_wave;
+  float* Vsh = Ksh + T * HD;
+  float* Qsh = Vsh + T * HD;   // scaled q
+  float* Gsh = Qsh + T * HD;   // dO
+  float* Ssh = Gsh + T * HD;   // P then dS
+  float* Bsh = Ssh + T * TS;   // per-head table gradient
+  int bid = blockIdx.x;
+  const int wx = bid % d.nwx; bid /= d.nwx;
+  const int wy = bid % d.nwy;
+  const int n = bid / d.nwy;
+  const long long HW = (long long)d.H * d.W;
+  const float* base = d.qkv + (long long)n * 3 * d.C * HW;
+  float* dbase = d.dqkv + (long long)n * 3 * d.C * HW;
+  const bool active = lane < T;
+  const Tok me = token(d, wy, wx, active ? lane : 0);
+
+  for (int head = wave; head < d.heads; head += nwaves) {
+    const float* qp = base + (long long)(head * HD) * HW;
+    const float* kp = base + (long long)(d.C + head * HD) * HW;
+    const float* vp = base + (long long)(2 * d.C + head * HD) * HW;
+    const float* gp = d.dout + ((long long)n * d.C + head * HD) * HW;
+    float q[HD], go[HD];
+    for (int i = lane; i < ntab; i += 64) Bsh[i] = 0.0f;
+    if (active) {
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) {
+        q[dd] = qp[dd * HW + me.pix] * d.scale;
+        go[dd] = gp[dd * HW + me.pix];
+        Qsh[lane * HD + dd] = q[dd];
+        Gsh[lane * HD + dd] = go[dd];
+        Ksh[lane * HD + dd] = kp[dd * HW + me.pix];
+        Vsh[lane * HD + dd] = vp[dd * HW + me.pix];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- recompute P (row per lane)
+    float inv = 0.0f;
+    if (active) {
+      float m = -3.0e38f;
+      for (int j = 0; j < T; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) s += q[dd] * Ksh[j * HD + dd];
+        const Tok tj = token(d, wy, wx, j);
+        const int idx = (me.r - tj.r + d.ws - 1) * tw + (me.c - tj.c + d.ws - 1);
+        s += d.table[idx * d.heads + head];
+        if (d.shift > 0 && tj.lab != me.lab) s += -100.0f;
+        Ssh[lane * TS + j] = s;
+        m = fmaxf(m, s);
+      }
+      float l = 0.0f;
+      for (int j = 0; j < T; ++j) {
+        const float p = expf(Ssh[lane * TS + j] - m);
+        Ssh[lane * TS + j] = p;
+        l += p;
+      }
+      inv = 1.0f / l;
+      for (int j = 0; j < T; ++j) Ssh[lane * TS + j] *= inv;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- dV[j][:] = sum_i P[i][j] dO[i][:]   (lane = j, column sweep of P)
+    if (active) {
+      float acc[HD];
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) acc[dd] = 0.0f;
+      for (int i = 0; i < T; ++i) {
+        const float p = Ssh[i * TS + lane];
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) acc[dd] += p * Gsh[i * HD + dd];
+      }
+      float* dv = dbase + (long long)(2 * d.C + head * HD) * HW;
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) dv[dd * HW + me.pix] = acc[dd];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- dP, delta, dS (row per lane), dq, table gradient
+    if (active) {
+      float delta = 0.0f;
+      for (int j = 0; j < T; ++j) {
+        float dp = 0.0f;
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) dp += go[dd] * Vsh[j * HD + dd];
+        delta += Ssh[lane * TS + j] * dp;
+      }
+      float dq[HD];
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) dq[dd] = 0.0f;
+      for (int j = 0; j < T; ++j) {
+        float dp = 0.0f;
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) dp += go[dd] * Vsh[j * HD + dd];
+        const float ds = Ssh[lane * TS + j] * (dp - delta);
+        Ssh[lane * TS + j] = ds;
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) dq[dd] += ds * Ksh[j * HD + dd];
+        const Tok tj = token(d, wy, wx, j);
+        const int idx = (me.r - tj.r + d.ws - 1) * tw + (me.c - tj.c + d.ws - 1);
+        Bsh[idx] += ds;  // distinct idx across the active lanes of this instruction
+      }
+      float* dqp = dbase + (long long)(head * HD) * HW;
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) dqp[dd * HW + me.pix] = dq[dd] * d.scale;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- dK[j][:] = sum_i dS[i][j] q[i][:]   (lane = j)
+    if (active) {
+      float acc[HD];
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) acc[dd] = 0.0f;
+      for (int i = 0; i < T; ++i) {
+        const float ds = Ssh[i * TS + lane];
+#pragma unroll
+        for (int dd = 0; dd < HD; ++dd) acc[dd] += ds * Qsh[i * HD + dd];
+      }
+      float* dk = dbase + (long long)(d.C + head * HD) * HW;
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) dk[dd * HW + me.pix] = acc[dd];
+    }
+    for (int i = lane; i < ntab; i += 64) {
+      const float v = Bsh[i];
+      if (v != 0.0f) atomicAdd(d.dtable + i * d.heads + head, v);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+typedef void (*WaFn)(const WaDesc);
+template <int HD> struct WaK {
+  static WaFn fwd() { return winattn_fwd_kernel<HD>; }
+  static WaFn bwd() { return winattn_bwd_kernel<HD>; }
+};
+static bool pick(int hd, WaFn& f, WaFn& b) {
+  switch (hd) {
+#define C_(n) case n: f = WaK<n>::fwd(); b = WaK<n>::bwd(); return true;
+    C_(8) C_(10) C_(16) C_(24) C_(32) C_(40) C_(48)
+#undef C_
+    default: return false;
+  }
+}
+
+static int fill_desc(WaDesc& d, int N, int C, int H, int W, int heads, int ws, int shift) {
+  if (N <= 0 || C <= 0 || heads <= 0 || C % heads != 0 || ws <= 0) return ICM_ERR_ARG;
+  if (shift < 0 || shift >= ws) return ICM_ERR_ARG;            // assert at win_attention.py:144
+  if (H % ws != 0 || W % ws != 0) return ICM_ERR_ARG;          // view() would raise in window_partition
+  if (ws * ws > 64) return ICM_ERR_UNSUPPORTED;
+  d.N = N; d.C = C; d.H = H; d.W = W; d.heads = heads; d.ws = ws; d.shift = shift; d.hd = C / heads;
+  d.T = ws * ws; d.nwx = W / ws; d.nwy = H / ws;
+  d.scale = 1.0f / sqrtf((float)d.hd);
+  return ICM_OK;
+}
+
+}  // namespace icm
+
+using namespace icm;
+extern "C" {
+
+int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W, int heads, int ws,
+                    int shift, void* stream) {
+  if (!qkv || !table || !out) return ICM_ERR_ARG;
+  WaDesc d{};
+  int rc = fill_desc(d, N, C, H, W, heads, ws, shift);
+  if (rc) return rc;
+  d.qkv = qkv; d.table = table; d.out = out;
+  WaFn f, b;
+  if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
+  const int waves = std::min(4, heads);
+  const size_t lds = (size_t)waves * (2 * d.T * d.hd + d.T * (d.T + 1)) * 4;
+  if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(f, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable, int N, int C,
+                    int H, int W, int heads, int ws, int shift, void* stream) {
+  if (!qkv || !table || !dout || !dqkv || !dtable) return ICM_ERR_ARG;
+  WaDesc d{};
+  int rc = fill_desc(d, N, C, H, W, heads, ws, shift);
+  if (rc) return rc;
+  d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable = dtable;
+  WaFn f, b;
+  if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
+  const int waves = std::min(2, heads);
+  const int tw = 2 * ws - 1;
+  const size_t lds = (size_t)waves * (4 * d.T * d.hd + d.T * (d.T + 1) + tw * tw) * 4;
+  if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+}  // extern "C"

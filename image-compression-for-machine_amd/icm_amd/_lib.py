@@ -1,0 +1,148 @@
+"""ctypes binding of libicm_hip.so (the C ABI declared in include/icm_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libicm_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_SQUARE = 0, 1, 2
+EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_GDN, EPI_IGDN, EPI_MUL_DGELU, EPI_AXPY2, EPI_LRP = range(8)
+
+_f = C.POINTER(C.c_float)
+i64, i32, f32, vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x_bs", i64), ("N", i32), ("Cin", i32), ("H", i32), ("W", i32),
+        ("wp", vp), ("bias", vp),
+        ("y", vp), ("y_bs", i64), ("Cout", i32), ("OH", i32), ("OW", i32),
+        ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
+        ("transposed", i32), ("pro_act", i32), ("epi", i32),
+        ("res", vp), ("res_bs", i64), ("aux", vp), ("aux_bs", i64), ("aux2", vp), ("aux2_bs", i64),
+        ("y2", vp), ("y2_bs", i64),
+        ("accum", i32), ("pixel_shuffle", i32),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("gs", vp), ("gs_bs", i64), ("Ca", i32), ("OH", i32), ("OW", i32), ("act_s", i32),
+        ("gb", vp), ("gb_bs", i64), ("Cb", i32), ("H", i32), ("W", i32), ("act_b", i32),
+        ("N", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
+        ("dw", vp), ("ws", vp), ("accum", i32),
+    ]
+
+
+class EbParams(C.Structure):
+    _fields_ = [("matrix", vp * 5), ("bias", vp * 5), ("factor", vp * 4), ("quantiles", vp)]
+
+
+class EbGrads(C.Structure):
+    _fields_ = [("matrix", vp * 5), ("bias", vp * 5), ("factor", vp * 4), ("dmedian", vp)]
+
+
+class IcmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/icm_hip.h declares (tests check that the .so exports them all)
+SYMBOLS = [
+    "icm_strerror", "icm_version", "icm_conv_run", "icm_conv_run_grouped", "icm_conv2d_fwd", "icm_conv2d_dgrad",
+    "icm_convT2d_fwd", "icm_convT2d_dgrad", "icm_packed_weight_floats", "icm_pack_weights",
+    "icm_wgrad_workspace_floats", "icm_conv_wgrad", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
+    "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
+    "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
+    "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
+    "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IcmError(
+                f"{LIB_PATH} not found: build it with image-compression-for-machine_amd/build.sh "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.icm_strerror.restype = C.c_char_p
+        L.icm_packed_weight_floats.restype = i64
+        L.icm_wgrad_workspace_floats.restype = i64
+        L.icm_packed_weight_floats.argtypes = [i32, i32, i32, i32]
+        L.icm_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]
+        L.icm_conv_run.argtypes = [C.POINTER(ConvArgs), vp]
+        L.icm_conv_run_grouped.argtypes = [C.POINTER(ConvArgs), i32, vp]
+        for n in ("icm_conv2d_fwd", "icm_conv2d_dgrad", "icm_convT2d_fwd", "icm_convT2d_dgrad"):
+            getattr(L, n).argtypes = [C.POINTER(ConvArgs), vp]
+        L.icm_wgrad_workspace_floats.argtypes = [C.POINTER(WgradArgs)]
+        L.icm_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
+        L.icm_channel_sum.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp]
+        L.icm_nonneg_fwd.argtypes = [vp, vp, i64, f32, f32, vp]
+        L.icm_nonneg_bwd.argtypes = [vp, vp, vp, i64, f32, i32, vp]
+        L.icm_gdn_bwd_pre.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
+        L.icm_gelu_fwd.argtypes = [vp, vp, i64, vp]
+        L.icm_gate_fwd.argtypes = [vp, vp, vp, vp, i64, vp]
+        L.icm_gate_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]
+        L.icm_add_grad.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.icm_ste_round_offset.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        L.icm_lrp_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
+        L.icm_pixel_unshuffle2.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.icm_copy_strided.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, vp]
+        L.icm_winattn_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.icm_winattn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.icm_eb_likelihood_fwd.argtypes = [vp, vp, C.POINTER(EbParams), vp, vp, i32, i32, i32, f32, vp]
+        L.icm_eb_likelihood_bwd.argtypes = [vp, vp, C.POINTER(EbParams), vp, vp, C.POINTER(EbGrads), i32, i32, i32,
+                                            f32, i32, vp]
+        L.icm_eb_aux_loss.argtypes = [C.POINTER(EbParams), vp, vp, i32, f32, vp]
+        L.icm_gc_likelihood_ste_fwd.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32,
+                                                i32, i32, f32, f32, vp]
+        L.icm_gc_likelihood_ste_bwd.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp,
+                                                i64, vp, i64, i32, i32, i32, f32, f32, i32, vp]
+        L.icm_rd_loss_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, vp, vp]
+        L.icm_rd_loss_bwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, f32, vp, vp, vp, vp]
+        L.icm_grad_sqnorm.argtypes = [vp, i64, vp, vp]
+        L.icm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, f32, f32, vp]
+        L.icm_fill.argtypes = [vp, i64, f32, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().icm_strerror(rc).decode()
+        if rc == 1:
+            raise ValueError(f"icm {what}: {msg}")
+        raise IcmError(f"icm {what}: {msg} (code {rc})")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def bs(t) -> int:
+    """batch stride (floats) of a [N,C,H,W] tensor whose C/H/W strides are canonical (channel slices allowed)."""
+    if t is None:
+        return 0
+    assert t.dtype == torch.float32 and t.is_cuda, "icm ops need float32 device tensors"
+    if t.dim() == 4:
+        N, Cc, H, W = t.shape
+        st = t.stride()
+        assert (W == 1 or st[3] == 1) and (H == 1 or st[2] == W) and (Cc == 1 or st[1] == H * W), \
+            f"non-canonical plane strides {st} for shape {tuple(t.shape)}"
+        return st[0] if N > 1 else Cc * H * W
+    assert t.is_contiguous()
+    return t[0].numel() if t.dim() > 0 else 1

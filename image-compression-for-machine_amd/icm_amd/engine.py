@@ -1,0 +1,518 @@
+"""Execution engine: a tape of HIP-kernel launches with hand-scheduled backward closures.
+
+Every numeric op of the hot path is a call into libicm_hip.so (``_lib``).  PyTorch supplies device memory
+(the caching allocator), streams and the autograd *bridge* (``tape_function``) so that reference-style
+training loops (``loss.backward()``) work unchanged; the gradient math itself is the closures below.
+
+Conventions
+  * tensors are float32 NCHW device tensors; channel slices of a larger buffer are legal everywhere;
+  * ``VT(t, act)`` is a *virtual* tensor: the value is ``act(t)`` but only the pre-activation ``t`` is ever
+    stored -- consumers apply ``act`` while staging their operand into LDS, and backward multiplies by
+    ``act'(t)`` in the producing dgrad's epilogue;
+  * gradient buffers: first writer overwrites, later writers accumulate (``Tape.grad_for_write``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_GELU, ACT_NONE, ACT_SQUARE, EPI_AXPY2, EPI_GDN, EPI_IGDN, EPI_LRP, EPI_MUL_DGELU, EPI_NONE,
+                   EPI_RES, EPI_RES_GELU, bs, check, ptr)
+
+PEDESTAL = 2.0 ** -36
+
+
+def new(shape_or_like, device=None):
+    """fresh contiguous f32 device tensor (torch caching allocator = device memory plumbing)"""
+    if isinstance(shape_or_like, torch.Tensor):
+        return torch.empty(shape_or_like.shape, dtype=torch.float32, device=shape_or_like.device)
+    return torch.empty(shape_or_like, dtype=torch.float32, device=device)
+
+
+def zeros(shape, device):
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
+class VT:
+    """virtual tensor: value = act(t)"""
+    __slots__ = ("t", "act")
+
+    def __init__(self, t: torch.Tensor, act: int = ACT_NONE):
+        self.t, self.act = t, act
+
+
+def _key(t: torch.Tensor):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+
+class Tape:
+    def __init__(self, need_grad: bool = True):
+        self.need_grad = need_grad
+        self.bw: List[Callable[[], None]] = []
+        self.grads: Dict[tuple, torch.Tensor] = {}
+        self.ready = set()
+        self.stopped = set()
+        self._packed: Dict[tuple, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+        self.st = L.stream()
+
+    # ---- gradient bookkeeping
+    def stop(self, t):
+        self.stopped.add(_key(t))
+
+    def wants(self, t) -> bool:
+        return self.need_grad and _key(t) not in self.stopped
+
+    def bind_grad(self, t, g, initialized: bool):
+        k = _key(t)
+        self.grads[k] = g
+        if initialized:
+            self.ready.add(k)
+        else:
+            self.ready.discard(k)
+
+    def grad_for_write(self, t) -> Tuple[torch.Tensor, int]:
+        k = _key(t)
+        g = self.grads.get(k)
+        if g is None:
+            g = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+            self.grads[k] = g
+        accum = 1 if k in self.ready else 0
+        self.ready.add(k)
+        return g, accum
+
+    def grad_of(self, t) -> Optional[torch.Tensor]:
+        k = _key(t)
+        return self.grads.get(k) if k in self.ready else None
+
+    def backward(self):
+        for f in reversed(self.bw):
+            f()
+        self.bw = []
+
+    # ---- helpers
+    def workspace(self, nfloats: int, device) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nfloats:
+            self._ws = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
+        return self._ws
+
+    def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0):
+        k = (w.data_ptr(), w._version, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg)
+        wp = self._packed.get(k)
+        if wp is None:
+            n = L.lib().icm_packed_weight_floats(M, K, KH, KW)
+            wp = torch.empty(n, dtype=torch.float32, device=w.device)
+            check(L.lib().icm_pack_weights(ptr(w), ptr(wp), M, K, KH, KW, src_out_major, transposed, stride, pad,
+                                           nonneg, bound, ped, self.st), "pack_weights")
+            self._packed[k] = wp
+        return wp
+
+
+# ------------------------------------------------------------------------------------------------ raw launches
+def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW, pro_act=ACT_NONE,
+                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0):
+    a = L.ConvArgs()
+    N, _, H, W = x.shape
+    a.x, a.x_bs, a.N, a.Cin, a.H, a.W = ptr(x), bs(x), N, Cin, H, W
+    a.wp, a.bias = ptr(wp), ptr(bias)
+    a.y, a.y_bs, a.Cout, a.OH, a.OW = ptr(y), bs(y), Cout, OH, OW
+    a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+    a.transposed, a.pro_act, a.epi = int(transposed), pro_act, epi
+    a.res, a.res_bs = ptr(res), bs(res)
+    a.aux, a.aux_bs = ptr(aux), bs(aux)
+    a.aux2, a.aux2_bs = ptr(aux2), bs(aux2)
+    a.y2, a.y2_bs = ptr(y2), bs(y2)
+    a.accum, a.pixel_shuffle = accum, ps
+    check(L.lib().icm_conv_run(C.byref(a), tape.st), "conv_run")
+
+
+def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0):
+    a = L.WgradArgs()
+    N, _, OH, OW = gs.shape
+    _, _, H, W = gb.shape
+    a.gs, a.gs_bs, a.Ca, a.OH, a.OW, a.act_s = ptr(gs), bs(gs), Ca, OH, OW, act_s
+    a.gb, a.gb_bs, a.Cb, a.H, a.W, a.act_b = ptr(gb), bs(gb), Cb, H, W, act_b
+    a.N, a.KH, a.KW, a.stride, a.pad = N, KH, KW, stride, pad
+    a.dw, a.accum = ptr(dw), accum
+    a.ws = 0
+    n = L.lib().icm_wgrad_workspace_floats(C.byref(a))
+    if n < 0:
+        raise ValueError("icm wgrad: invalid geometry")
+    ws = tape.workspace(n, gs.device)
+    a.ws = ptr(ws)
+    check(L.lib().icm_conv_wgrad(C.byref(a), tape.st), "conv_wgrad")
+
+
+def accumulate(tape, dst_t, src, mul_dgelu_of=None):
+    """grad(dst_t) (+)= src * gelu'(mul_dgelu_of)"""
+    if not tape.wants(dst_t):
+        return
+    g, acc = tape.grad_for_write(dst_t)
+    if g.is_contiguous() and src.is_contiguous() and (mul_dgelu_of is None or mul_dgelu_of.is_contiguous()):
+        check(L.lib().icm_add_grad(ptr(src), ptr(mul_dgelu_of), ptr(g), src.numel(), acc, tape.st), "add_grad")
+    else:
+        assert mul_dgelu_of is None
+        N, Cc = src.shape[0], src.shape[1]
+        HW = src.shape[2] * src.shape[3]
+        check(L.lib().icm_copy_strided(ptr(src), bs(src), ptr(g), bs(g), N, Cc, HW, acc, tape.st), "copy_strided")
+
+
+def copy_into(tape, src, dst, accum=0):
+    N, Cc = src.shape[0], src.shape[1]
+    HW = src.shape[2] * src.shape[3]
+    check(L.lib().icm_copy_strided(ptr(src), bs(src), ptr(dst), bs(dst), N, Cc, HW, accum, tape.st), "copy_strided")
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, output_padding=0, res: Optional[VT] = None,
+           out=None, pixel_shuffle=0, lrp_aux=None) -> torch.Tensor:
+    """nn.Conv2d / nn.ConvTranspose2d / nn.Linear(on NCHW) forward with fused neighbours.  Returns the
+    pre-activation output tensor (or y_hat for the LRP epilogue)."""
+    x, act = xv.t, xv.act
+    N, Cin, H, W = x.shape
+    w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+    if not transposed:
+        Cout, ci, KH, KW = w4.shape
+        OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+        wp = tape.pack(w4, Cout, Cin, KH, KW, 1, 0, stride, pad)
+    else:
+        ci, Cout, KH, KW = w4.shape
+        OH = (H - 1) * stride - 2 * pad + KH + output_padding
+        OW = (W - 1) * stride - 2 * pad + KW + output_padding
+        wp = tape.pack(w4, Cout, Cin, KH, KW, 0, 1, stride, pad)
+    if ci != Cin:
+        raise ValueError(f"conv2d: weight expects {ci} input channels, got {Cin}")
+    if pixel_shuffle == 2:
+        oshape = (N, Cout // 4, OH * 2, OW * 2)
+    else:
+        oshape = (N, Cout, OH, OW)
+    y = out if out is not None else torch.empty(oshape, dtype=torch.float32, device=x.device)
+    assert tuple(y.shape) == oshape, (tuple(y.shape), oshape)
+    epi, resv, aux, y2 = EPI_NONE, None, None, None
+    if res is not None:
+        epi = EPI_RES_GELU if res.act == ACT_GELU else EPI_RES
+        assert res.act in (ACT_NONE, ACT_GELU)
+        resv = res.t
+    if lrp_aux is not None:
+        assert res is None
+        epi, aux = EPI_LRP, lrp_aux
+        y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    conv_launch(tape, x, wp, b, y, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, transposed=transposed,
+                OH=OH, OW=OW, pro_act=act, epi=epi, res=resv, aux=aux, y2=y2, ps=pixel_shuffle)
+    if not tape.need_grad:
+        return y
+
+    def bwd():
+        dy = tape.grad_of(y)
+        if dy is None:
+            return
+        if lrp_aux is not None:
+            accumulate(tape, lrp_aux, dy)
+            dpre = torch.empty(oshape, dtype=torch.float32, device=x.device)
+            check(L.lib().icm_lrp_bwd(ptr(dy), bs(dy), ptr(y2), bs(y2), ptr(dpre), bs(dpre), N, Cout, OH * OW, tape.st),
+                  "lrp_bwd")
+            dy = dpre
+        if pixel_shuffle == 2:
+            du = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+            assert dy.is_contiguous()
+            check(L.lib().icm_pixel_unshuffle2(ptr(dy), ptr(du), N, Cout // 4, OH, OW, tape.st), "pixel_unshuffle2")
+            dy = du
+        if res is not None:
+            accumulate(tape, res.t, dy, res.t if res.act == ACT_GELU else None)
+        if b is not None and tape.wants(b):
+            gb_, acc = tape.grad_for_write(b)
+            check(L.lib().icm_channel_sum(ptr(dy), bs(dy), N, Cout, OH * OW, ptr(gb_), acc, tape.st), "channel_sum")
+        if tape.wants(w):
+            gw, acc = tape.grad_for_write(w)
+            if not transposed:
+                wgrad_launch(tape, dy, x, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=act,
+                             accum=acc)
+            else:
+                wgrad_launch(tape, x, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=act,
+                             accum=acc)
+        if tape.wants(x):
+            gx, acc = tape.grad_for_write(x)
+            if act == ACT_GELU:
+                epi_b, aux_b = EPI_MUL_DGELU, x
+            elif act == ACT_NONE:
+                epi_b, aux_b = EPI_NONE, None
+            else:
+                raise NotImplementedError("dgrad through this virtual activation")
+            if not transposed:   # conv dgrad = scatter with W ([K=Cout][M=Cin])
+                wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad)
+                conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
+                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, accum=acc)
+            else:                # convT dgrad = gather with Wt ([M=Cin][K=Cout])
+                wpb = tape.pack(w4, Cin, Cout, KH, KW, 1, 0, stride, pad)
+                conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
+                            transposed=0, OH=H, OW=W, epi=epi_b, aux=aux_b, accum=acc)
+
+    tape.bw.append(bwd)
+    return y
+
+
+def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> torch.Tensor:
+    """GDN / IGDN (layers/gdn.py:62-75): one 1x1 implicit GEMM with x^2 prologue and rsqrt/sqrt epilogue."""
+    N, Cc, H, W = x.shape
+    if gamma.shape != (Cc, Cc) or beta.shape != (Cc,):
+        raise ValueError("GDN: channel mismatch")
+    bound_b = (beta_min + PEDESTAL) ** 0.5
+    bound_g = PEDESTAL ** 0.5
+    beta_eff = torch.empty_like(beta)
+    check(L.lib().icm_nonneg_fwd(ptr(beta), ptr(beta_eff), Cc, bound_b, PEDESTAL, tape.st), "nonneg_fwd")
+    wp = tape.pack(gamma, Cc, Cc, 1, 1, 1, 0, 1, 0, nonneg=1, bound=bound_g, ped=PEDESTAL)
+    y = new(x)
+    nrm = new(x) if tape.need_grad else None
+    conv_launch(tape, x, wp, beta_eff, y, Cin=Cc, Cout=Cc, KH=1, KW=1, stride=1, pad=0, transposed=0, OH=H, OW=W,
+                pro_act=ACT_SQUARE, epi=EPI_IGDN if inverse else EPI_GDN, aux=x, y2=nrm)
+    if not tape.need_grad:
+        return y
+
+    def bwd():
+        g = tape.grad_of(y)
+        if g is None:
+            return
+        g = g if g.is_contiguous() else g.contiguous()
+        dn = new(x)
+        t1 = new(x)
+        xc = x if x.is_contiguous() else x.contiguous()
+        check(L.lib().icm_gdn_bwd_pre(ptr(g), ptr(xc), ptr(nrm), ptr(dn), ptr(t1), x.numel(), int(inverse), tape.st),
+              "gdn_bwd_pre")
+        if tape.wants(beta):
+            de = torch.empty_like(beta)
+            check(L.lib().icm_channel_sum(ptr(dn), bs(dn), N, Cc, H * W, ptr(de), 0, tape.st), "channel_sum")
+            gb_, acc = tape.grad_for_write(beta)
+            check(L.lib().icm_nonneg_bwd(ptr(beta), ptr(de), ptr(gb_), Cc, bound_b, acc, tape.st), "nonneg_bwd")
+        if tape.wants(gamma):
+            dg = torch.empty_like(gamma)
+            wgrad_launch(tape, dn, x, dg, Ca=Cc, Cb=Cc, KH=1, KW=1, stride=1, pad=0, act_b=ACT_SQUARE)
+            gg, acc = tape.grad_for_write(gamma)
+            check(L.lib().icm_nonneg_bwd(ptr(gamma), ptr(dg), ptr(gg), Cc * Cc, bound_g, acc, tape.st), "nonneg_bwd")
+        if tape.wants(x):
+            gx, acc = tape.grad_for_write(x)
+            wpt = tape.pack(gamma, Cc, Cc, 1, 1, 0, 0, 1, 0, nonneg=1, bound=bound_g, ped=PEDESTAL)
+            conv_launch(tape, dn, wpt, None, gx, Cin=Cc, Cout=Cc, KH=1, KW=1, stride=1, pad=0, transposed=0, OH=H,
+                        OW=W, epi=EPI_AXPY2, aux=x, aux2=t1, accum=acc)
+
+    tape.bw.append(bwd)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ attention gate
+def residual_unit(tape, xv: VT, P, p) -> VT:
+    """layers/layers.py:52-72 with virtual GELUs: returns VT(pre, GELU)."""
+    u1 = conv2d(tape, xv, P[p + ".conv.0.weight"], P[p + ".conv.0.bias"])
+    u2 = conv2d(tape, VT(u1, ACT_GELU), P[p + ".conv.2.weight"], P[p + ".conv.2.bias"], pad=1)
+    u3 = conv2d(tape, VT(u2, ACT_GELU), P[p + ".conv.4.weight"], P[p + ".conv.4.bias"], res=xv)
+    return VT(u3, ACT_GELU)
+
+
+def window_attention(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
+    """WinBasedAttention.forward (layers/win_attention.py:153-207): x + proj(attn(qkv(x)))."""
+    N, Cc, H, W = x.shape
+    if not (0 <= shift < ws):
+        raise AssertionError("shift_size must in 0-window_size")
+    table = P[p + ".attn.relative_position_bias_table"]
+    qkv = conv2d(tape, VT(x), P[p + ".attn.qkv.weight"], P[p + ".attn.qkv.bias"])
+    o = new(x)
+    check(L.lib().icm_winattn_fwd(ptr(qkv), ptr(table), ptr(o), N, Cc, H, W, heads, ws, shift, tape.st), "winattn_fwd")
+    if tape.need_grad:
+        def bwd():
+            do = tape.grad_of(o)
+            if do is None:
+                return
+            dqkv, acc = tape.grad_for_write(qkv)
+            assert acc == 0
+            gt, acct = tape.grad_for_write(table)
+            if not acct:
+                check(L.lib().icm_fill(ptr(gt), gt.numel(), 0.0, tape.st), "fill")
+            check(L.lib().icm_winattn_bwd(ptr(qkv), ptr(table), ptr(do), ptr(dqkv), ptr(gt), N, Cc, H, W, heads, ws,
+                                          shift, tape.st), "winattn_bwd")
+        tape.bw.append(bwd)
+    return conv2d(tape, VT(o), P[p + ".attn.proj.weight"], P[p + ".attn.proj.bias"], res=VT(x))
+
+
+def attention_gate(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
+    """Win_noShift_Attention.forward (layers/layers.py:83-89): a*sigmoid(b) + x."""
+    a = VT(x)
+    for i in range(3):
+        a = residual_unit(tape, a, P, f"{p}.conv_a.{i}")
+    b = VT(window_attention(tape, x, P, p + ".conv_b.0", heads, ws, shift))
+    for i in (1, 2, 3):
+        b = residual_unit(tape, b, P, f"{p}.conv_b.{i}")
+    b4 = conv2d(tape, b, P[p + ".conv_b.4.weight"], P[p + ".conv_b.4.bias"])
+    out = new(x)
+    xc = x if x.is_contiguous() else x.contiguous()
+    check(L.lib().icm_gate_fwd(ptr(a.t), ptr(b4), ptr(xc), ptr(out), x.numel(), tape.st), "gate_fwd")
+    if tape.need_grad:
+        def bwd():
+            g = tape.grad_of(out)
+            if g is None:
+                return
+            g = g if g.is_contiguous() else g.contiguous()
+            da, acca = tape.grad_for_write(a.t)
+            db, accb = tape.grad_for_write(b4)
+            assert accb == 0
+            if tape.wants(x):
+                dx, accx = tape.grad_for_write(x)
+                assert dx.is_contiguous()
+            else:
+                dx, accx = torch.empty_like(xc), 0
+            check(L.lib().icm_gate_bwd(ptr(g), ptr(a.t), ptr(b4), ptr(da), ptr(db), ptr(dx), x.numel(), acca, accx,
+                                       tape.st), "gate_bwd")
+        tape.bw.append(bwd)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ entropy models
+EB_NAMES = [f"_matrix{i}" for i in range(5)] + [f"_bias{i}" for i in range(5)] + [f"_factor{i}" for i in range(4)]
+
+
+def _eb_params(P, p):
+    s = L.EbParams()
+    for i in range(5):
+        s.matrix[i] = ptr(P[f"{p}._matrix{i}"])
+        s.bias[i] = ptr(P[f"{p}._bias{i}"])
+    for i in range(4):
+        s.factor[i] = ptr(P[f"{p}._factor{i}"])
+    s.quantiles = ptr(P[f"{p}.quantiles"])
+    return s
+
+
+def eb_likelihood(tape, z, P, p="entropy_bottleneck", noise=None, lik_bound=1e-9, want_zt=False):
+    """EntropyBottleneck.forward (entropy_models.py:446-489) -> (z_tilde or None, likelihood)."""
+    N, Cc = z.shape[0], z.shape[1]
+    HW = z[0, 0].numel()
+    zc = z if z.is_contiguous() else z.contiguous()
+    if P[f"{p}._matrix0"].shape[0] != Cc:
+        raise ValueError("EntropyBottleneck: channel mismatch")
+    lik = torch.empty_like(zc)
+    zt = torch.empty_like(zc) if want_zt else None
+    prm = _eb_params(P, p)
+    check(L.lib().icm_eb_likelihood_fwd(ptr(zc), ptr(noise), C.byref(prm), ptr(lik), ptr(zt), N, Cc, HW, lik_bound,
+                                        tape.st), "eb_fwd")
+    if tape.need_grad:
+        def bwd():
+            dl = tape.grad_of(lik)
+            if dl is None:
+                return
+            dl = dl if dl.is_contiguous() else dl.contiguous()
+            g = L.EbGrads()
+            for i in range(5):
+                gm, a1 = tape.grad_for_write(P[f"{p}._matrix{i}"])
+                gb_, a2 = tape.grad_for_write(P[f"{p}._bias{i}"])
+                assert a1 == 0 and a2 == 0
+                g.matrix[i], g.bias[i] = ptr(gm), ptr(gb_)
+            for i in range(4):
+                gf, a3 = tape.grad_for_write(P[f"{p}._factor{i}"])
+                assert a3 == 0
+                g.factor[i] = ptr(gf)
+            dmed = None
+            if noise is None:
+                dmed = torch.empty(Cc, dtype=torch.float32, device=z.device)
+                g.dmedian = ptr(dmed)
+            if tape.wants(z):
+                dz, acc = tape.grad_for_write(z)
+                assert dz.is_contiguous()
+            else:
+                dz, acc = torch.empty_like(zc), 0
+            check(L.lib().icm_eb_likelihood_bwd(ptr(zc), ptr(noise), C.byref(prm), ptr(dl), ptr(dz), C.byref(g), N, Cc,
+                                                HW, lik_bound, acc, tape.st), "eb_bwd")
+            if dmed is not None and tape.wants(P[f"{p}.quantiles"]):
+                gq, accq = tape.grad_for_write(P[f"{p}.quantiles"])
+                if not accq:
+                    gq.zero_()
+                gq[:, 0, 1] += dmed
+        tape.bw.append(bwd)
+    return zt, lik
+
+
+def ste_round_medians(tape, z, quantiles):
+    """z_hat = ste_round(z - med) + med (cnn.py:150-152)."""
+    N, Cc = z.shape[0], z.shape[1]
+    zc = z if z.is_contiguous() else z.contiguous()
+    zh = torch.empty_like(zc)
+    check(L.lib().icm_ste_round_offset(ptr(zc), ptr(quantiles), ptr(zh), N, Cc, z[0, 0].numel(), tape.st), "ste_round")
+    if tape.need_grad:
+        def bwd():
+            g = tape.grad_of(zh)
+            if g is not None:
+                accumulate(tape, z, g)
+        tape.bw.append(bwd)
+    return zh
+
+
+def gc_likelihood_ste(tape, y, mu, scale, noise, lik_out, yh_out, yh2_out=None, scale_bound=0.11, lik_bound=1e-9):
+    """GaussianConditional.forward fused with ste_round(y-mu)+mu (entropy_models.py:645-659, cnn.py:171-173)."""
+    N, Cc, H, W = y.shape
+    check(L.lib().icm_gc_likelihood_ste_fwd(ptr(y), bs(y), ptr(mu), bs(mu), ptr(scale), bs(scale), ptr(noise),
+                                            bs(noise), ptr(lik_out), bs(lik_out), ptr(yh_out), bs(yh_out),
+                                            ptr(yh2_out), bs(yh2_out), N, Cc, H * W, scale_bound, lik_bound, tape.st),
+          "gc_fwd")
+    if tape.need_grad:
+        def bwd():
+            dl = tape.grad_of(lik_out)
+            dyh = tape.grad_of(yh_out) if yh_out is not None else None
+            if dl is None and dyh is None:
+                return
+            if dl is None:
+                dl = torch.zeros((N, Cc, H, W), dtype=torch.float32, device=y.device)
+            dy, acc = tape.grad_for_write(y)
+            dmu, a1 = tape.grad_for_write(mu)
+            dsc, a2 = tape.grad_for_write(scale)
+            assert a1 == 0 and a2 == 0
+            check(L.lib().icm_gc_likelihood_ste_bwd(ptr(y), bs(y), ptr(mu), bs(mu), ptr(scale), bs(scale), ptr(noise),
+                                                    bs(noise), ptr(dl), bs(dl), ptr(dyh), bs(dyh), ptr(dy), bs(dy),
+                                                    ptr(dmu), bs(dmu), ptr(dsc), bs(dsc), N, Cc, H * W, scale_bound,
+                                                    lik_bound, acc, tape.st), "gc_bwd")
+        tape.bw.append(bwd)
+
+
+# ------------------------------------------------------------------------------------------------ autograd bridge
+class _TapeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, nstop, *tensors):
+        tape = Tape(need_grad=True)
+        outs = runner(tape, *tensors)
+        ctx.tape, ctx.tensors, ctx.outs = tape, tensors, outs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        tape = ctx.tape
+        tape.st = L.stream()
+        for o, g in zip(ctx.outs, gouts):
+            if g is not None:
+                tape.bind_grad(o, g.contiguous(), True)
+        tape.backward()
+        res = []
+        for t, need in zip(ctx.tensors, ctx.needs_input_grad[2:]):
+            res.append(tape.grad_of(t) if need else None)
+        ctx.tape = None
+        return (None, None, *res)
+
+
+def tape_function(runner, tensors: Sequence[torch.Tensor]):
+    """Run ``runner(tape, *tensors) -> tuple(outputs)`` as ONE autograd node whose backward is the tape."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        return _TapeFn.apply(_Needs(runner, tensors), 0, *tensors)
+    tape = Tape(need_grad=False)
+    with torch.no_grad():
+        return tuple(runner(tape, *[t.detach() for t in tensors]))
+
+
+class _Needs:
+    """callable wrapper that marks non-differentiable inputs as stopped before running"""
+
+    def __init__(self, runner, tensors):
+        self.runner = runner
+        self.flags = [bool(t.requires_grad) for t in tensors]
+
+    def __call__(self, tape, *ts):
+        for t, f in zip(ts, self.flags):
+            if not f:
+                tape.stop(t)
+        return self.runner(tape, *ts)

@@ -1,0 +1,4 @@
+"""compressai/zoo mirror restricted to the hot path (zoo/__init__.py:23-43)."""
+from .models import WACNN
+
+models = {"cnn": WACNN}

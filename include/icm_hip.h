@@ -1,0 +1,203 @@
+/* icm_hip.h -- C ABI of libicm_hip.so: the MI355X (gfx950) hot path of the `cnn` (WACNN) codec.
+ *
+ * Drop-in boundary.  The reference has no FFI on this path: every op below
+ * replaces a call the reference makes into ATen from Python.  Each entry point cites the
+ * reference call site it stands in for (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - all tensors are device pointers to IEEE f32, NCHW, contiguous planes (H*W); the batch
+ *     stride of every tensor is explicit (in floats) so channel-slices of a larger buffer
+ *     (torch.cat / chunk in compressai/models/cnn.py:157-183) are addressed without copies;
+ *   - `stream` is a hipStream_t; kernels are enqueued on it; nothing allocates, frees or
+ *     synchronises (graph-capture safe);
+ *   - return value: 0 = ok, ICM_ERR_* otherwise (icm_strerror()).
+ */
+#ifndef ICM_HIP_H
+#define ICM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICM_OK 0
+#define ICM_ERR_ARG 1      /* bad argument (mirrors the reference's ValueError / assert sites) */
+#define ICM_ERR_LAUNCH 2   /* hipLaunch failed */
+#define ICM_ERR_UNSUPPORTED 3
+
+/* activation applied to an operand while it is staged into LDS ("virtual" activations: the
+ * framework stores pre-activations only; nn.GELU at layers/layers.py:59-63, cnn.py:54-127) */
+#define ICM_ACT_NONE 0
+#define ICM_ACT_GELU 1     /* exact erf GELU */
+#define ICM_ACT_SQUARE 2   /* x*x: GDN's conv2d(x**2, gamma) (layers/gdn.py:68) */
+
+/* epilogues of the implicit-GEMM kernels */
+#define ICM_EPI_NONE 0        /* y = acc + bias */
+#define ICM_EPI_RES 1         /* y = acc + bias + res              (out += identity, layers.py:69) */
+#define ICM_EPI_RES_GELU 2    /* y = acc + bias + gelu(res)        (identity is a virtual GELU output) */
+#define ICM_EPI_GDN 3         /* y2 = n = acc + bias; y = aux * rsqrt(n)   (gdn.py:68-75) */
+#define ICM_EPI_IGDN 4        /* y2 = n;              y = aux * sqrt(n)    (gdn.py:70-71) */
+#define ICM_EPI_MUL_DGELU 5   /* y = acc * gelu'(aux)              (backward through a virtual GELU) */
+#define ICM_EPI_AXPY2 6       /* y = aux2 + 2*aux*acc              (GDN backward dx) */
+#define ICM_EPI_LRP 7         /* y = aux + 0.5*tanh(acc + bias); y2 = tanh(...)  (cnn.py:175-178) */
+
+const char* icm_strerror(int code);
+int icm_version(void);
+
+/* ---- implicit-GEMM convolution family (f32 MFMA) ------------------------------------------
+ * Replaces nn.Conv2d / nn.ConvTranspose2d / nn.Linear forward and backward:
+ *   models/utils.py:114-132 (conv, deconv), layers/layers.py:29-43 (conv3x3, subpel_conv3x3, conv1x1),
+ *   layers/gdn.py:68 (the CxC contraction), layers/win_attention.py:77-79,91,112 (qkv / proj Linear).
+ *
+ * transposed = 0  "gather":  y[n,o,p]        = sum_{i,t} Wg[o][i][t] * act(x[n,i,p*stride - pad + t])
+ * transposed = 1  "scatter": y[n,o,q]        = sum_{i,t,p : p*stride - pad + t == q} Ws[i][o][t] * act(x[n,i,p])
+ * conv fwd = gather with W; conv dgrad = scatter with W; convT fwd = scatter with Wt;
+ * convT dgrad = gather with Wt.  Weights are passed pre-packed (icm_pack_weights).
+ */
+typedef struct icm_conv_args {
+  const float* x; int64_t x_bs; int N, Cin, H, W;
+  const float* wp;
+  const float* bias;
+  float* y; int64_t y_bs; int Cout, OH, OW;
+  int KH, KW, stride, pad;
+  int transposed;
+  int pro_act;
+  int epi;
+  const float* res; int64_t res_bs;
+  const float* aux; int64_t aux_bs;
+  const float* aux2; int64_t aux2_bs;
+  float* y2; int64_t y2_bs;
+  int accum;          /* y += result instead of y = result (gradient accumulation) */
+  int pixel_shuffle;  /* 2: fuse nn.PixelShuffle(2) into the store (layers.py:34-38); y plane is (2*OH,2*OW), Cout/4 channels */
+} icm_conv_args;
+
+int icm_conv_run(const icm_conv_args* a, void* stream);
+/* up to 3 problems of identical geometry in one launch (cc_mean || cc_scale chains, cnn.py:164-168) */
+int icm_conv_run_grouped(const icm_conv_args* a, int ngroups, void* stream);
+/* named views of icm_conv_run, one per reference op */
+int icm_conv2d_fwd(const icm_conv_args* a, void* stream);     /* F.conv2d forward            */
+int icm_conv2d_dgrad(const icm_conv_args* a, void* stream);   /* its input gradient          */
+int icm_convT2d_fwd(const icm_conv_args* a, void* stream);    /* F.conv_transpose2d forward  */
+int icm_convT2d_dgrad(const icm_conv_args* a, void* stream);  /* its input gradient          */
+
+/* number of floats of a packed weight buffer for GEMM-M `Cout`, GEMM-K channels `Cin` */
+int64_t icm_packed_weight_floats(int Cout, int Cin, int KH, int KW);
+/* w: canonical weights. src_out_major=1: w is [Cout][Cin][KH][KW] (Conv2d.weight seen by conv fwd,
+ * ConvTranspose2d.weight seen by convT dgrad); 0: w is [Cin][Cout][KH][KW].  transposed/stride/pad
+ * select the tap order the consuming icm_conv_run call expects.  nonneg=1 applies
+ * NonNegativeParametrizer (ops/parametrizers.py:46-49): max(w,bound)^2 - pedestal while packing. */
+int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int KW, int src_out_major,
+                     int transposed, int stride, int pad, int nonneg, float bound, float pedestal,
+                     void* stream);
+
+/* weight gradient: dW[a][b][t] = sum_{n,p} actS(gs[n,a,p]) * actB(gb[n,b,p*stride - pad + t])
+ * conv:  gs = dY (a = Cout), gb = x  (b = Cin) -> Conv2d.weight.grad
+ * convT: gs = x  (a = Cin),  gb = dY (b = Cout) -> ConvTranspose2d.weight.grad
+ * ws: workspace of icm_wgrad_workspace_floats(...) floats. accum: dw += result. */
+typedef struct icm_wgrad_args {
+  const float* gs; int64_t gs_bs; int Ca, OH, OW; int act_s;
+  const float* gb; int64_t gb_bs; int Cb, H, W; int act_b;
+  int N, KH, KW, stride, pad;
+  float* dw; float* ws; int accum;
+} icm_wgrad_args;
+int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a);
+int icm_conv_wgrad(const icm_wgrad_args* a, void* stream);
+
+/* out[c] (+)= sum_{n,p} x[n,c,p]   (bias gradients; GDN d_beta) */
+int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, void* stream);
+
+/* ---- GDN helpers (layers/gdn.py:62-75, ops/parametrizers.py:46-49, ops/bound_ops.py:25-27) ---- */
+int icm_nonneg_fwd(const float* p, float* out, int64_t n, float bound, float pedestal, void* stream);
+/* dp (+)= lb_bwd(2*max(p,bound)*g_eff) */
+int icm_nonneg_bwd(const float* p, const float* g_eff, float* dp, int64_t n, float bound, int accum, void* stream);
+/* dn = g*x*(-/+ 1/2)*n^(-/+1/2 - 1), t1 = g*n^(-/+ 1/2) */
+int icm_gdn_bwd_pre(const float* g, const float* x, const float* nrm, float* dn, float* t1, int64_t n, int inverse, void* stream);
+
+/* ---- elementwise pieces of Win_noShift_Attention (layers/layers.py:83-89) and cnn.py:150-152 ---- */
+int icm_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+/* out = gelu(a) * sigmoid(b) + x  (a is the virtual-GELU pre-activation of conv_a) */
+int icm_gate_fwd(const float* a_pre, const float* b, const float* x, float* out, int64_t n, void* stream);
+/* da_pre (+)= g*sig(b)*gelu'(a_pre); db = g*gelu(a_pre)*sig(b)*(1-sig(b)); dx (+)= g */
+int icm_gate_bwd(const float* g, const float* a_pre, const float* b, float* da_pre, float* db, float* dx,
+                 int64_t n, int accum_da, int accum_dx, void* stream);
+/* dst (+)= src * (mul_dgelu_of ? gelu'(mul_dgelu_of) : 1) */
+int icm_add_grad(const float* src, const float* mul_dgelu_of, float* dst, int64_t n, int accum, void* stream);
+/* z_hat[n,c,p] = rint(z - med[c]) - (z-med[c]) + (z-med[c]) + med[c]   (ops/ops.py:34, cnn.py:150-152) */
+int icm_ste_round_offset(const float* z, const float* quantiles, float* z_hat, int N, int C, int HW, void* stream);
+/* LRP tail backward (cnn.py:177-178): dpre = g * 0.5 * (1 - t*t), t = tanh saved by ICM_EPI_LRP */
+int icm_lrp_bwd(const float* g, int64_t g_bs, const float* t, int64_t t_bs, float* dpre, int64_t d_bs, int N, int C,
+                int HW, void* stream);
+/* inverse of nn.PixelShuffle(2) (layers.py:34-38) for the subpel conv backward: src [N][C][2H][2W] -> dst [N][4C][H][W] */
+int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+/* strided 4-D copy (chunk/cat plumbing): dst[n,c,p] (+)= src[n,c,p] */
+int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int N, int C, int HW, int accum, void* stream);
+
+/* ---- window attention core (layers/win_attention.py:84-115,153-207) --------------------------
+ * qkv: [N][3*C][H][W] (output of the qkv Linear run as a 1x1 conv on NCHW; channel = which*C + head*hd + d)
+ * out: [N][C][H][W] (channel = head*hd + d), input of the proj Linear.  Cyclic shift, window partition,
+ * relative-position bias gather, the 0/-100 shift mask and the softmax are folded into addressing.
+ * table: relative_position_bias_table [(2ws-1)^2][heads]. */
+int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W,
+                    int heads, int ws, int shift, void* stream);
+/* dqkv = gradient wrt qkv (overwritten), dtable (+)= gradient wrt table (must be zeroed by caller if !accum) */
+int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
+                    int N, int C, int H, int W, int heads, int ws, int shift, void* stream);
+
+/* ---- EntropyBottleneck (entropy_models.py:395-433,446-489) ---------------------------------
+ * params: the 13 tensors concatenated per channel is NOT required; pointers are passed separately.
+ * z [N][C][HW]; noise NULL -> eval (dequantize around medians) else z + noise.
+ * lik out [N][C][HW]; zt (z tilde) optional out. */
+typedef struct icm_eb_params {
+  const float* matrix[5]; const float* bias[5]; const float* factor[4]; const float* quantiles;
+} icm_eb_params;
+typedef struct icm_eb_grads {
+  float* matrix[5]; float* bias[5]; float* factor[4];
+  float* dmedian; /* [C], eval mode only (z~ = round(z-med)+med passes gradient to med, not z); may be NULL */
+} icm_eb_grads;
+int icm_eb_likelihood_fwd(const float* z, const float* noise, const icm_eb_params* p, float* lik, float* zt,
+                          int N, int C, int HW, float lik_bound, void* stream);
+/* dz (+)= ..., param grads overwritten (one workgroup owns a channel: deterministic) */
+int icm_eb_likelihood_bwd(const float* z, const float* noise, const icm_eb_params* p, const float* dlik,
+                          float* dz, const icm_eb_grads* g, int N, int C, int HW, float lik_bound,
+                          int accum_dz, void* stream);
+/* aux loss = sum |F(quantiles) - target| and its gradient wrt quantiles (entropy_models.py:395-398) */
+int icm_eb_aux_loss(const icm_eb_params* p, float* loss /*1 float, overwritten*/, float* dquantiles, int C,
+                    float target, void* stream);
+
+/* ---- GaussianConditional likelihood fused with ste_round (entropy_models.py:626-659, cnn.py:171-173)
+ * y slice [N][C][HW] with batch stride y_bs; mu/scale [N][C][HW] with strides; noise may be NULL (eval).
+ * lik -> [N][C][HW] (lik_bs); y_hat = ste_round(y-mu)+mu -> (yh_bs), optional second copy yh2. */
+int icm_gc_likelihood_ste_fwd(const float* y, int64_t y_bs, const float* mu, int64_t mu_bs, const float* scale,
+                              int64_t sc_bs, const float* noise, int64_t nz_bs, float* lik, int64_t lik_bs,
+                              float* yh, int64_t yh_bs, float* yh2, int64_t yh2_bs, int N, int C, int HW,
+                              float scale_bound, float lik_bound, void* stream);
+/* inputs: dlik, dyh (gradient wrt y_hat_pre; may be NULL). outputs: dy (+)=, dmu =, dscale = */
+int icm_gc_likelihood_ste_bwd(const float* y, int64_t y_bs, const float* mu, int64_t mu_bs, const float* scale,
+                              int64_t sc_bs, const float* noise, int64_t nz_bs, const float* dlik, int64_t dl_bs,
+                              const float* dyh, int64_t dyh_bs, float* dy, int64_t dy_bs, float* dmu, int64_t dmu_bs,
+                              float* dscale, int64_t dsc_bs, int N, int C, int HW, float scale_bound,
+                              float lik_bound, int accum_dy, void* stream);
+
+/* ---- R-D loss (train.py:53-61, train_czigzag.py:63,71) --------------------------------------
+ * out[0]=bpp, out[1]=mse, out[2]=loss, out[3]=sum log(lik_y), out[4]=sum log(lik_z); out must be
+ * zeroed by the caller (5 floats); two launches (reduce, finish). */
+int icm_rd_loss_fwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
+                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, void* stream);
+/* dx_hat = gscale * lmbda*255^2*2*(x_hat-x)/n ; dlik = gscale * -1/(lik*ln2*num_pixels) */
+int icm_rd_loss_bwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
+                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float gscale,
+                    float* dx_hat, float* dlik_y, float* dlik_z, void* stream);
+
+/* ---- optimiser (train.py:105-169,199-214) ---------------------------------------------------- */
+/* out[0] += sum g^2 (caller zeroes) */
+int icm_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
+/* Adam step with fused clip: coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6)) if sqnorm!=NULL else 1;
+ * g is scaled by gscale (1/world_size) then coef; torch.optim.Adam defaults semantics. */
+int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream);
+int icm_fill(float* p, int64_t n, float v, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

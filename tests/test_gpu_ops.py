@@ -1,0 +1,361 @@
+"""GPU parity: every HIP op (through the Python mirror -> ctypes -> C ABI) against the CPU oracle.
+
+Tolerances: all arithmetic is IEEE f32; the f32 MFMA is an exact fmaf chain, so differences to the CPU
+reference are summation-order noise.  ``TOL`` is relative to the reference tensor's max magnitude.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import wacnn_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def U(key, shape, lo=-1.0, hi=1.0):
+    return W._u(key, shape, lo, hi)
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ref = max(b.abs().max().item(), 1e-30)
+    d = (a - b).abs().max().item()
+    assert math.isfinite(d) and d <= tol * ref, f"{what}: maxdiff {d:.3e} vs ref max {ref:.3e} (rel {d/ref:.2e})"
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+# ------------------------------------------------------------------------------------------ conv family
+CONV_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, transposed
+    ("c5s2_3_192", 2, 3, 32, 32, 192, 5, 2, False),
+    ("c5s2_192_192", 2, 192, 16, 16, 192, 5, 2, False),
+    ("c5s2_40_320_odd", 1, 40, 24, 40, 320, 5, 2, False),
+    ("c3s1_96_96", 2, 96, 16, 16, 96, 3, 1, False),
+    ("c3s2_72_56", 3, 72, 8, 8, 56, 3, 2, False),
+    ("c3s1_tiny4x4", 4, 24, 4, 4, 48, 3, 1, False),
+    ("c3s1_176", 2, 64, 16, 16, 176, 3, 1, False),
+    ("c1_192_96", 2, 192, 16, 16, 96, 1, 1, False),
+    ("c1_20_576", 1, 20, 8, 24, 576, 1, 1, False),
+    ("t5s2_320_192", 2, 320, 8, 8, 192, 5, 2, True),
+    ("t5s2_64_3", 2, 64, 16, 16, 3, 5, 2, True),
+    ("t5s2_24_40_odd", 1, 24, 6, 10, 40, 5, 2, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(case):
+    from icm_amd import layers
+    name, N, Cin, H, Wd, Cout, k, s, tr = case
+    d = dev()
+    if tr:
+        m = layers.deconv(Cin, Cout, kernel_size=k, stride=s)
+    else:
+        m = layers.Conv2d(Cin, Cout, kernel_size=k, stride=s, padding=k // 2)
+    w = U(name + ".w", m.weight.shape, -0.2, 0.2)
+    b = U(name + ".b", m.bias.shape, -0.5, 0.5)
+    x = U(name + ".x", (N, Cin, H, Wd), -1.0, 1.0)
+    # reference
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if tr:
+        yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=k // 2, output_padding=s - 1)
+    else:
+        yr = F.conv2d(xr, wr, br, stride=s, padding=k // 2)
+    g = U(name + ".g", yr.shape, -1.0, 1.0)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], g)
+    # HIP
+    m = m.to(d)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.bias.copy_(b)
+    xg = x.to(d).requires_grad_(True)
+    y = m(xg)
+    close(y, yr, what="y")
+    gx, gw, gb = torch.autograd.grad(y, [xg, m.weight, m.bias], g.to(d))
+    close(gx, gxr, what="dx")
+    close(gw, gwr, what="dw")
+    close(gb, gbr, what="db")
+
+
+def test_conv_every_tile_config():
+    """every template instantiation of the implicit-GEMM kernel gives the same answer"""
+    import ctypes
+    from icm_amd import _lib, layers
+    d = dev()
+    lib = _lib.lib()
+    lib.icm_debug_force_conv_cfg.argtypes = [ctypes.c_int]
+    lib.icm_debug_force_conv_cfg.restype = None
+    m = layers.Conv2d(40, 200, kernel_size=3, stride=1, padding=1)
+    w = U("cfg.w", m.weight.shape, -0.2, 0.2)
+    b = U("cfg.b", m.bias.shape, -0.5, 0.5)
+    x = U("cfg.x", (3, 40, 20, 36), -1.0, 1.0)
+    yr = F.conv2d(x, w, b, padding=1)
+    m = m.to(d)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.bias.copy_(b)
+    try:
+        for cfg in range(8):
+            lib.icm_debug_force_conv_cfg(cfg)
+            with torch.no_grad():
+                y = m(x.to(d))
+            close(y, yr, what=f"cfg{cfg}")
+    finally:
+        lib.icm_debug_force_conv_cfg(-1)
+
+
+def test_conv_argument_errors():
+    from icm_amd import layers
+    d = dev()
+    m = layers.Conv2d(8, 8, kernel_size=3, padding=1).to(d)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 8, 8, device=d))
+
+
+# ------------------------------------------------------------------------------------------ GDN
+@pytest.mark.parametrize("name,inverse", [("gdn", False), ("igdn", True)])
+def test_gdn_golden(golden_dir, name, inverse):
+    from icm_amd import layers
+    f = load(golden_dir, name)
+    d = dev()
+    m = layers.GDN(f["x"].shape[1], inverse=inverse).to(d)
+    with torch.no_grad():
+        m.beta.copy_(f["beta"])
+        m.gamma.copy_(f["gamma"])
+    x = f["x"].to(d).requires_grad_(True)
+    y = m(x)
+    close(y, f["y"], what="y")
+    gx, gb, gg = torch.autograd.grad(y, [x, m.beta, m.gamma], f["g"].to(d))
+    close(gx, f["gx"], what="gx")
+    close(gb, f["gbeta"], what="gbeta")
+    close(gg, f["ggamma"], what="ggamma")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_192_vs_oracle(inverse):
+    from icm_amd import layers
+    d = dev()
+    C = 192
+    beta = math.sqrt(1 + W.PEDESTAL) + U("g192.beta", (C,), -0.2, 0.3)
+    gamma = torch.sqrt(0.1 * torch.eye(C) + W.PEDESTAL) + U("g192.gamma", (C, C), -0.004, 0.012)
+    x = U("g192.x", (2, C, 32, 32), -2, 2)
+    g = U("g192.g", (2, C, 32, 32), -1, 1)
+    xr, br, gr = (t.clone().requires_grad_(True) for t in (x, beta, gamma))
+    yr = O.gdn(xr, br, gr, inverse)
+    gxr, gbr, ggr = torch.autograd.grad(yr, [xr, br, gr], g)
+    m = layers.GDN(C, inverse=inverse).to(d)
+    with torch.no_grad():
+        m.beta.copy_(beta)
+        m.gamma.copy_(gamma)
+    xg = x.to(d).requires_grad_(True)
+    y = m(xg)
+    close(y, yr, what="y")
+    gx, gb, gg = torch.autograd.grad(y, [xg, m.beta, m.gamma], g.to(d))
+    close(gx, gxr, what="gx")
+    close(gb, gbr, what="gbeta")
+    close(gg, ggr, what="ggamma")
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("tag,dim,ws,shift", [("wa_d64_ws8", 64, 8, 4), ("wa_d80_ws4", 80, 4, 2),
+                                              ("wa_d64_ws8_noshift", 64, 8, 0)])
+def test_window_attention_golden(golden_dir, tag, dim, ws, shift):
+    from icm_amd import layers
+    f = load(golden_dir, tag)
+    d = dev()
+    m = layers.WinBasedAttention(dim=dim, num_heads=8, window_size=ws, shift_size=shift).to(d)
+    with torch.no_grad():
+        m.attn.qkv.weight.copy_(f["attn.qkv.weight"])
+        m.attn.qkv.bias.copy_(f["attn.qkv.bias"])
+        m.attn.proj.weight.copy_(f["attn.proj.weight"])
+        m.attn.proj.bias.copy_(f["attn.proj.bias"])
+        m.attn.relative_position_bias_table.copy_(f["attn.relative_position_bias_table"])
+    x = f["x"].to(d).requires_grad_(True)
+    y = m(x)
+    close(y, f["y"], what="y")
+    ps = [m.attn.qkv.weight, m.attn.qkv.bias, m.attn.proj.weight, m.attn.proj.bias, m.attn.relative_position_bias_table]
+    gs = torch.autograd.grad(y, [x] + ps, f["g"].to(d))
+    for a, k in zip(gs, ["gx", "g_qkv_w", "g_qkv_b", "g_proj_w", "g_proj_b", "g_table"]):
+        close(a, f[k], 5e-5, what=k)
+
+
+@pytest.mark.parametrize("dim,ws,shift,hw", [(192, 8, 4, 16), (320, 4, 2, 8)])
+def test_attention_gate_vs_oracle(dim, ws, shift, hw):
+    from icm_amd import layers
+    d = dev()
+    tag = f"gate{dim}"
+    m = layers.Win_noShift_Attention(dim=dim, num_heads=8, window_size=ws, shift_size=shift)
+    sd = {}
+    for k, v in m.state_dict().items():
+        leaf = k.rsplit(".", 1)[-1]
+        if not v.dtype.is_floating_point:
+            sd[k] = v
+        elif leaf == "relative_position_bias_table":
+            sd[k] = U(tag + k, v.shape, -0.5, 0.5)
+        elif leaf == "weight":
+            bnd = 1.0 / math.sqrt(int(np.prod(v.shape[1:])))
+            sd[k] = U(tag + k, v.shape, -bnd, bnd) * 1.7
+        else:
+            sd[k] = U(tag + k, v.shape, -0.1, 0.1)
+    m.load_state_dict(sd)
+    x = U(tag + ".x", (2, dim, hw, hw), -1.5, 1.5)
+    g = U(tag + ".g", (2, dim, hw, hw), -1, 1)
+    osd = {"p." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.win_attention_gate(xr, osd, "p", 8, ws, shift)
+    names = [n for n, _ in m.named_parameters()]
+    grs = torch.autograd.grad(yr, [xr] + [osd["p." + n] for n in names], g)
+    m = m.to(d)
+    xg = x.to(d).requires_grad_(True)
+    y = m(xg)
+    close(y, yr, what="y")
+    gs = torch.autograd.grad(y, [xg] + [p for _, p in m.named_parameters()], g.to(d))
+    for a, b, n in zip(gs, grs, ["x"] + names):
+        close(a, b, 1e-4, what="grad " + n)
+
+
+# ------------------------------------------------------------------------------------------ entropy models
+def test_entropy_bottleneck_golden(golden_dir):
+    from icm_amd.entropy_models import EntropyBottleneck
+    f = load(golden_dir, "entropy_bottleneck")
+    d = dev()
+    pn = [k[1:] for k in f if k.startswith("p_") or k == "pquantiles"]
+    eb = EntropyBottleneck(f["z"].shape[1]).to(d)
+    with torch.no_grad():
+        for n in pn:
+            getattr(eb, n).copy_(f["p" + n])
+    for mode in ("eval", "train"):
+        eb.train(mode == "train")
+        eb.inject_noise(f["noise"].to(d) if mode == "train" else None)
+        for gname in ("g", "gpos"):
+            z = f["z"].to(d).requires_grad_(True)
+            zt, lik = eb(z)
+            close(zt, f[mode + "_zt"], 1e-6, what=mode + " zt")
+            close(lik, f[mode + "_lik"], what=mode + " lik")
+            ps = [getattr(eb, n) for n in pn]
+            gs = torch.autograd.grad(lik, [z] + ps, f[gname].to(d), allow_unused=True)
+            gs = [torch.zeros_like(t) if a is None else a for a, t in zip(gs, [z] + ps)]
+            close(gs[0], f[f"{mode}_{gname}_gz"], 5e-5, what=f"{mode} {gname} gz")
+            for n, a in zip(pn, gs[1:]):
+                ref = f[f"{mode}_{gname}_grad{n}"]
+                if ref.abs().max() == 0:
+                    assert a.abs().max().item() == 0, n
+                else:
+                    close(a, ref, 1e-4, what=f"{mode} {gname} grad {n}")
+    aux = eb.loss()
+    assert abs(aux.item() - f["aux"].item()) <= 1e-5 * abs(f["aux"].item())
+    (gq,) = torch.autograd.grad(aux, [eb.quantiles])
+    close(gq, f["aux_gq"], 1e-5, what="aux gq")
+
+
+def test_gaussian_conditional_golden(golden_dir):
+    from icm_amd.entropy_models import GaussianConditional
+    f = load(golden_dir, "gaussian_conditional")
+    d = dev()
+    gc = GaussianConditional(None).to(d)
+    for mode in ("eval", "train"):
+        gc.train(mode == "train")
+        gc.inject_noise(f["noise"].to(d) if mode == "train" else None)
+        for gname in ("g", "gpos"):
+            y, mu, sc = (f[k].to(d).requires_grad_(True) for k in ("y", "mu", "sc"))
+            yt, lik = gc(y, sc, mu)
+            close(yt, f[mode + "_yt"], 1e-6, what="yt")
+            ref = f[mode + "_lik"]
+            dd = (lik.cpu() - ref).abs()
+            assert (dd <= 2e-6 + 2e-5 * ref).all(), f"{mode} lik maxdiff {dd.max().item()}"
+            gy, gm, gs = torch.autograd.grad(lik, [y, mu, sc], f[gname].to(d), allow_unused=True)
+            gy = torch.zeros_like(y) if gy is None else gy
+            gm = torch.zeros_like(mu) if gm is None else gm
+            close(gy, f[f"{mode}_{gname}_gy"], 5e-5, what=f"{mode} {gname} gy")
+            close(gm, f[f"{mode}_{gname}_gmu"], 5e-5, what=f"{mode} {gname} gmu")
+            close(gs, f[f"{mode}_{gname}_gsc"], 5e-5, what=f"{mode} {gname} gsc")
+
+
+def test_gaussian_conditional_errors():
+    from icm_amd.entropy_models import GaussianConditional
+    with pytest.raises(ValueError):
+        GaussianConditional([3.0, 1.0])
+    with pytest.raises(ValueError):
+        GaussianConditional(None, scale_bound=0.0)
+    with pytest.raises(ValueError):
+        GaussianConditional("x")
+
+
+def test_ops_golden(golden_dir):
+    from icm_amd import ops
+    f = load(golden_dir, "ops")
+    d = dev()
+    x = f["ste_x"].to(d).requires_grad_(True)
+    y = ops.ste_round(x)
+    assert torch.equal(y.cpu(), f["ste_y"])
+    (gx,) = torch.autograd.grad(y, [x], torch.arange(12, dtype=torch.float32, device=d))
+    assert torch.equal(gx.cpu(), f["ste_gx"])
+    lb = ops.LowerBound(0.11).to(d)
+    x = f["lb_x"].to(d).requires_grad_(True)
+    y = lb(x)
+    assert torch.equal(y.cpu(), f["lb_y"])
+    (gx,) = torch.autograd.grad(y, [x], f["lb_g"].to(d))
+    assert torch.equal(gx.cpu(), f["lb_gx"])
+    par = ops.NonNegativeParametrizer(minimum=1e-6).to(d)
+    x = f["nn_x"].to(d).requires_grad_(True)
+    y = par(x)
+    close(y, f["nn_y"], 1e-6, what="nonneg")
+    (gx,) = torch.autograd.grad(y, [x], f["nn_g"].to(d))
+    close(gx, f["nn_gx"], 1e-6, what="nonneg grad")
+
+
+# ------------------------------------------------------------------------------------------ loss / optimiser
+def test_rd_loss_and_adam():
+    from icm_amd import _lib as L
+    from icm_amd.losses import RateDistortionLoss
+    d = dev()
+    x = U("rd.x", (2, 3, 64, 64), 0, 1)
+    xh = (x + U("rd.e", x.shape, -0.3, 0.3)).requires_grad_(True)
+    ly = U("rd.ly", (2, 320, 4, 4), 1e-4, 1.0).requires_grad_(True)
+    lz = U("rd.lz", (2, 192, 1, 1), 1e-3, 1.0).requires_grad_(True)
+    ref = O.rd_loss(x, {"x_hat": xh, "likelihoods": {"y": ly, "z": lz}}, 0.0067)
+    gr = torch.autograd.grad(ref["loss"], [xh, ly, lz])
+    xg, xhg, lyg, lzg = x.to(d), xh.detach().to(d).requires_grad_(True), ly.detach().to(d).requires_grad_(True), \
+        lz.detach().to(d).requires_grad_(True)
+    out = RateDistortionLoss(0.0067)({"x_hat": xhg, "likelihoods": {"y": lyg, "z": lzg}}, xg)
+    for k in ("loss", "bpp_loss", "mse_loss"):
+        assert abs(out[k].item() - ref[k].item()) <= 2e-6 * abs(ref[k].item()), k
+    gg = torch.autograd.grad(out["loss"], [xhg, lyg, lzg])
+    for a, b, n in zip(gg, gr, ("dx_hat", "dlik_y", "dlik_z")):
+        close(a, b, 1e-5, what=n)
+    # Adam + clip against the oracle
+    n = 100003
+    p = U("ad.p", (n,), -1, 1)
+    g = U("ad.g", (n,), -2, 2)
+    m = torch.zeros(n)
+    v = torch.zeros(n)
+    pg, gg_, mg, vg = (t.clone().to(d) for t in (p, g, m, v))
+    sq = torch.zeros(1, device=d)
+    for step in (1, 2, 3):
+        gs = [g.clone()]
+        total = O.clip_grad_norm_(gs, 1.0)
+        O.adam_step(p, gs[0], m, v, step, 1e-4)
+        sq.zero_()
+        L.check(L.lib().icm_grad_sqnorm(L.ptr(gg_), n, L.ptr(sq), L.stream()))
+        assert abs(math.sqrt(sq.item()) - total.item()) <= 1e-5 * total.item()
+        L.check(L.lib().icm_adam_step(L.ptr(pg), L.ptr(gg_), L.ptr(mg), L.ptr(vg), n, 1e-4, 0.9, 0.999, 1e-8, step,
+                                      L.ptr(sq), 1.0, 1.0, L.stream()))
+        close(pg, p, 1e-6, what=f"adam p step {step}")
+        close(mg, m, 1e-5, what="adam m")
+        close(vg, v, 1e-5, what="adam v")
