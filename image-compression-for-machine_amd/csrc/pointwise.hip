@@ -201,18 +201,17 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n
   block_atomic_add(s, out, red);
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt, const float* sqnorm, float max_norm, float gscale) {
+                            float* __restrict__ v, long long n, float step_size, float b1, float b2, float omb1,
+                            float omb2, float eps, float bc2_sqrt, const float* sqnorm, float max_norm, float gscale) {
   float coef = gscale;
   if (sqnorm) {
     const float total = sqrtf(*sqnorm) * gscale;
     coef *= fminf(1.0f, max_norm / (total + 1e-6f));
   }
-  const float step_size = lr / bc1;
   GRID_STRIDE(i, n) {
     const float gv = g[i] * coef;
-    const float mv = b1 * m[i] + (1.0f - b1) * gv;
-    const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+    const float mv = b1 * m[i] + omb1 * gv;
+    const float vv = b2 * v[i] + omb2 * gv * gv;
     m[i] = mv;
     v[i] = vv;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
@@ -341,13 +340,15 @@ int icm_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
-int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream) {
+int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step < 1) return ICM_ERR_ARG;
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
-                     bc1, bc2s, sqnorm, max_norm, gscale);
+  // scalars are formed in double exactly as torch.optim.Adam forms them on the host, then rounded to f32
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, (float)(lr / bc1),
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)bc2s,
+                     sqnorm, max_norm, gscale);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -111,7 +111,7 @@ def lib():
         L.icm_rd_loss_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, vp, vp]
         L.icm_rd_loss_bwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, f32, vp, vp, vp, vp]
         L.icm_grad_sqnorm.argtypes = [vp, i64, vp, vp]
-        L.icm_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp, f32, f32, vp]
+        L.icm_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp, f32, f32, vp]
         L.icm_fill.argtypes = [vp, i64, f32, vp]
         _lib = L
     return _lib

@@ -89,7 +89,8 @@ def _copy_op(tape, src, dst):
 
 
 def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise_z=None, noise_y=None,
-                  num_slices: int = 10, max_support: int = 5, keep: Optional[dict] = None):
+                  num_slices: int = 10, max_support: int = 5, keep: Optional[dict] = None,
+                  bucket_marks: Optional[dict] = None):
     """WACNN.forward (models/cnn.py:141-189) on the HIP engine -> (x_hat, y_likelihoods, z_likelihoods)."""
     dev = x.device
     N = x.shape[0]
@@ -113,6 +114,8 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
         tape.bind_grad(y, dY, True)
         for i in range(num_slices):
             tape.bind_grad(y[:, i * sc_:(i + 1) * sc_], dY[:, i * sc_:(i + 1) * sc_], True)
+    if bucket_marks is not None:
+        bucket_marks[2] = len(tape.bw)   # backward reaching here => hyper-path gradients are complete
     # ---- h_a + entropy bottleneck (cnn.py:144-152)
     z = _chain(tape, P, "h_a", VT(y), strides=(1, 1, 2, 1, 2))
     _, z_lik = E.eb_likelihood(tape, z, P, "entropy_bottleneck", noise_z)
@@ -142,6 +145,8 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
         for i in range(num_slices):
             tape.bind_grad(Y_hat[:, i * sc_:(i + 1) * sc_], dYh[:, i * sc_:(i + 1) * sc_], True)
     mus, scs = [], []
+    if bucket_marks is not None:
+        bucket_marks[1] = len(tape.bw)   # => slice-chain gradients complete
     # ---- channel-conditional slice loop (cnn.py:161-180)
     for i in range(num_slices):
         k = min(i, max_support)
@@ -166,6 +171,8 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
         if keep is not None:
             mus.append(mu)
             scs.append(sc)
+    if bucket_marks is not None:
+        bucket_marks[0] = len(tape.bw)   # => g_s gradients complete
     # ---- g_s (cnn.py:42-52)
     t = E.attention_gate(tape, Y_hat, P, "g_s.0", 8, 4, 2)
     t = E.conv2d(tape, VT(t), P["g_s.1.weight"], P["g_s.1.bias"], stride=2, pad=2, transposed=True, output_padding=1)

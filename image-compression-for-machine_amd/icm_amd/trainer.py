@@ -1,0 +1,201 @@
+"""Data-parallel training step for the `cnn` codec -- the semantics of the reference loop
+(train.py:188-214, configure_optimizers train.py:105-169) on the HIP engine, one process per GPU.
+
+    optimizer.zero_grad(); aux_optimizer.zero_grad()
+    out = model(x); loss = lmbda*255^2*mse + bpp; loss.backward()
+    clip_grad_norm_(model.parameters(), clip); optimizer.step()          # Adam on non-".quantiles"
+    aux = model.aux_loss(); aux.backward(); aux_optimizer.step()         # Adam(1e-4) on ".quantiles"
+
+The reference has no distributed code; data parallelism is added here the MI355X
+way: the batch is sharded over ranks, every parameter lives in ONE flat f32 buffer (so gradients are a
+single contiguous buffer too), gradient ranges are sum-all-reduced over RCCL/xGMI on a side stream as soon as
+the backward tape has passed the ops that produce them (4 large buckets, reverse topological order:
+g_s -> slice chains -> hyper path -> g_a), and clip + Adam run as two fused kernels over the flat buffers
+with the clip coefficient computed on the device (no host sync anywhere in the step).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import engine as E
+from ._lib import check, ptr
+from .models import wacnn_forward
+
+# bucket -> parameter-name prefixes, in the order their gradients complete during backward
+BUCKETS = [("g_s",), ("cc_mean_transforms", "cc_scale_transforms", "lrp_transforms"),
+           ("h_a", "h_mean_s", "h_scale_s", "entropy_bottleneck"), ("g_a",)]
+
+
+class FlatParams:
+    """All trainable tensors of a module re-homed into one flat buffer (views keep names/shapes)."""
+
+    def __init__(self, model: torch.nn.Module, device):
+        items = [(n, p) for n, p in model.named_parameters()]
+        self.main = [(n, p) for n, p in items if not n.endswith(".quantiles")]
+        self.aux = [(n, p) for n, p in items if n.endswith(".quantiles")]
+        # order the main parameters bucket by bucket so every bucket is one contiguous range
+        order: List[Tuple[str, torch.nn.Parameter]] = []
+        self.bucket_ranges: List[Tuple[int, int]] = []
+        off = 0
+        used = set()
+        for prefixes in BUCKETS:
+            start = off
+            for n, p in self.main:
+                if n.split(".")[0] in prefixes:
+                    order.append((n, p))
+                    used.add(n)
+                    off += (p.numel() + 3) // 4 * 4
+            self.bucket_ranges.append((start, off))
+        rest = [(n, p) for n, p in self.main if n not in used]
+        if rest:
+            start = off
+            for n, p in rest:
+                order.append((n, p))
+                off += (p.numel() + 3) // 4 * 4
+            self.bucket_ranges.append((start, off))
+        self.main = order
+        self.n_main = off
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+        self.views: Dict[str, torch.Tensor] = {}
+        self.gviews: Dict[str, torch.Tensor] = {}
+        o = 0
+        for n, prm in self.main:
+            k = prm.numel()
+            v = self.p[o:o + k].view(prm.shape)
+            v.copy_(prm.data.to(device))
+            prm.data = v
+            self.views[n] = v
+            self.gviews[n] = self.g[o:o + k].view(prm.shape)
+            o += (k + 3) // 4 * 4
+        na = sum(p.numel() for _, p in self.aux)
+        self.ap = torch.zeros(na, dtype=torch.float32, device=device)
+        self.ag = torch.zeros(na, dtype=torch.float32, device=device)
+        self.am = torch.zeros(na, dtype=torch.float32, device=device)
+        self.av = torch.zeros(na, dtype=torch.float32, device=device)
+        o = 0
+        for n, prm in self.aux:
+            k = prm.numel()
+            v = self.ap[o:o + k].view(prm.shape)
+            v.copy_(prm.data.to(device))
+            prm.data = v
+            self.views[n] = v
+            self.gviews[n] = self.ag[o:o + k].view(prm.shape)
+            o += k
+
+
+class GradReducer:
+    """Sum-all-reduce contiguous ranges of the flat gradient buffer on a side stream (RCCL over xGMI when
+    the process group is NCCL; gloo works for CPU tests)."""
+
+    def __init__(self, flat_g: torch.Tensor, ranges, group=None):
+        self.g, self.ranges, self.group = flat_g, list(ranges), group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.cuda = flat_g.is_cuda
+        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.works = []
+
+    def launch(self, bucket: int):
+        if self.world == 1:
+            return
+        a, b = self.ranges[bucket]
+        if b <= a:
+            return
+        t = self.g[a:b]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class Trainer:
+    def __init__(self, model, lr: float = 1e-4, aux_lr: float = 1e-4, lmbda: float = 0.0067,
+                 clip_max_norm: float = 1.0, device="cuda:0", group=None):
+        self.model = model.to(device).train()
+        self.device = torch.device(device)
+        self.flat = FlatParams(self.model, self.device)
+        self.lr, self.aux_lr, self.lmbda, self.clip = lr, aux_lr, lmbda, clip_max_norm
+        self.reducer = GradReducer(self.flat.g, self.flat.bucket_ranges, group)
+        self.world = self.reducer.world
+        self.step_no = 0
+        self.names = [n for n, _ in self.flat.main] + [n for n, _ in self.flat.aux]
+        self.scal = torch.zeros(8, dtype=torch.float32, device=self.device)  # [0:5] rd loss, [5] sqnorm, [6] aux
+        self._eb = None
+
+    def params(self) -> Dict[str, torch.Tensor]:
+        return self.flat.views
+
+    def step(self, x: torch.Tensor, noise: Optional[dict] = None) -> torch.Tensor:
+        """one training iteration on this rank's shard x [B,3,H,W]; returns the device tensor
+        [bpp, mse, loss, sumlog_y, sumlog_z, grad_sqnorm, aux_loss, -] (no host sync)."""
+        f, dev = self.flat, self.device
+        st = L.stream()
+        lib = L.lib()
+        self.step_no += 1
+        B, _, H, W = x.shape
+        if noise is None:
+            nz = torch.rand((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev) - 0.5
+            ny = torch.rand((B, 320, H // 16, W // 16), dtype=torch.float32, device=dev) - 0.5
+        else:
+            nz, ny = noise["z"].to(dev).contiguous(), noise["y"].to(dev).contiguous()
+        P = f.views
+        tape = E.Tape(need_grad=True)
+        tape.stop(x)
+        for n, _ in f.main:
+            tape.bind_grad(P[n], f.gviews[n], False)
+        marks = {}
+        x_hat, y_lik, z_lik = wacnn_forward(tape, P, x, nz, ny, bucket_marks=marks)
+        # ---- R-D loss forward + seeds (train.py:53-76)
+        self.scal.zero_()
+        check(lib.icm_rd_loss_fwd(ptr(x), ptr(x_hat), x.numel(), ptr(y_lik), y_lik.numel(), ptr(z_lik), z_lik.numel(),
+                                  B * H * W, self.lmbda, ptr(self.scal), st), "rd_loss_fwd")
+        dxh, dly, dlz = E.new(x_hat), E.new(y_lik), E.new(z_lik)
+        check(lib.icm_rd_loss_bwd(ptr(x), ptr(x_hat), x.numel(), ptr(y_lik), y_lik.numel(), ptr(z_lik), z_lik.numel(),
+                                  B * H * W, self.lmbda, 1.0, ptr(dxh), ptr(dly), ptr(dlz), st), "rd_loss_bwd")
+        tape.bind_grad(x_hat, dxh, True)
+        tape.bind_grad(y_lik, dly, True)
+        tape.bind_grad(z_lik, dlz, True)
+        # ---- backward with bucketed all-reduce overlapped (markers fire as the tape unwinds)
+        for name, idx in sorted(marks.items(), key=lambda kv: -kv[1]):
+            tape.bw.insert(idx, (lambda b=name: self.reducer.launch(b)))
+        tape.backward()
+        self.reducer.launch(len(BUCKETS) - 1)   # g_a: last gradients to complete
+        if len(f.bucket_ranges) > len(BUCKETS):
+            self.reducer.launch(len(BUCKETS))
+        self.reducer.finish()
+        # ---- clip (global L2 norm of the averaged gradients) + Adam, fused over the flat buffers
+        gscale = 1.0 / self.world
+        sq = self.scal[5:6]
+        check(lib.icm_grad_sqnorm(ptr(f.g), f.n_main, ptr(sq), st), "grad_sqnorm")
+        check(lib.icm_adam_step(ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.v), f.n_main, self.lr, 0.9, 0.999, 1e-8,
+                                self.step_no, ptr(sq) if self.clip > 0 else 0, float(self.clip), gscale, st), "adam")
+        # ---- aux loss on the UPDATED bottleneck weights, gradient to quantiles only (train.py:212-214)
+        prm = E._eb_params(P, "entropy_bottleneck")
+        t = math_target()
+        check(lib.icm_eb_aux_loss(C.byref(prm), ptr(self.scal[6:7]), ptr(f.ag), 192, t, st), "eb_aux")
+        check(lib.icm_adam_step(ptr(f.ap), ptr(f.ag), ptr(f.am), ptr(f.av), f.ap.numel(), self.aux_lr, 0.9, 0.999, 1e-8,
+                                self.step_no, 0, 0.0, 1.0, st), "adam_aux")
+        return self.scal
+
+
+def math_target(tail_mass: float = 1e-9) -> float:
+    import math
+    return math.log(2 / tail_mass - 1)

@@ -193,8 +193,8 @@ int icm_rd_loss_bwd(const float* x, const float* x_hat, int64_t n_img_elems, con
 int icm_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
 /* Adam step with fused clip: coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6)) if sqnorm!=NULL else 1;
  * g is scaled by gscale (1/world_size) then coef; torch.optim.Adam defaults semantics. */
-int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream);
+int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream);
 int icm_fill(float* p, int64_t n, float v, void* stream);
 
 #ifdef __cplusplus
