@@ -38,30 +38,74 @@ struct ConvPtrs {
 
 struct ConvDesc {
   ConvPtrs g[ICM_MAX_GROUPS];
-  long long x_bs, y_bs, res_bs, aux_bs, aux2_bs, y2_bs;
-  int N, Cin, H, W, Cout, OHf, OWf;
+  long long y_bs, res_bs, aux_bs, aux2_bs, y2_bs;
+  PatchGeom pg;                // input tensor + LDS patch layout
+  int Cout, OHf, OWf;
   int OHv, OWv;
   int out_sy, out_oy, out_sx, out_ox;
-  int iy0, ix0, S;
+  int iy0, ix0;
   int ntaps;
   int lgTW, lgTH, lgTI;
-  int PH, PW, PWh, PWrow, PP, CKS, lgPWp2;
-  FastDiv dTIPH, dPH;
   int tiles_x, tiles_y, tiles_n;
-  int ncot, nchunks, ncb;
-  int pro_act, epi, accum, ps2;
-  short tapoff[ICM_MAX_TAPS];
+  int ncot, nchunks8, ckm, ncb;
+  int epi, accum, ps2;
+  int tapoff[ICM_MAX_TAPS];   // dword entries: read with s_load (a 16-bit entry forces a VMEM load + vmcnt(0))
 };
 
+__device__ __forceinline__ void store_tile(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot,
+                                                     int h, int n, int oy, int ox, bool pvalid) {
+  const long long plane = (long long)d.OHf * d.OWf;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (!pvalid || co >= d.Cout) continue;
+    long long pix;
+    if (d.ps2) {
+      pix = (long long)(co >> 2) * plane + (long long)(oy * 2 + ((co >> 1) & 1)) * d.OWf + ox * 2 + (co & 1);
+    } else {
+      pix = (long long)co * plane + (long long)oy * d.OWf + ox;
+    }
+    float v = acc[r];
+    if (P.bias) v += P.bias[co];
+    switch (d.epi) {
+      case ICM_EPI_RES: v += P.res[n * d.res_bs + pix]; break;
+      case ICM_EPI_RES_GELU: v += gelu_f(P.res[n * d.res_bs + pix]); break;
+      case ICM_EPI_GDN: {
+        if (P.y2) P.y2[n * d.y2_bs + pix] = v;
+        v = P.aux[n * d.aux_bs + pix] * rsqrtf(v);
+      } break;
+      case ICM_EPI_IGDN: {
+        if (P.y2) P.y2[n * d.y2_bs + pix] = v;
+        v = P.aux[n * d.aux_bs + pix] * sqrtf(v);
+      } break;
+      case ICM_EPI_MUL_DGELU: v *= dgelu_f(P.aux[n * d.aux_bs + pix]); break;
+      case ICM_EPI_AXPY2: v = P.aux2[n * d.aux2_bs + pix] + 2.0f * P.aux[n * d.aux_bs + pix] * v; break;
+      case ICM_EPI_LRP: {
+        const float t = tanhf(v);
+        if (P.y2) P.y2[n * d.y2_bs + pix] = t;
+        v = P.aux[n * d.aux_bs + pix] + 0.5f * t;
+      } break;
+      default: break;
+    }
+    float* yp = P.y + n * d.y_bs + pix;
+    if (d.accum) v += *yp;
+    *yp = v;
+  }
+}
+
+// 512 threads: waves 0-3 issue MFMAs only (B fragments from LDS, A fragments = packed weights from L2);
+// waves 4-7 are loaders that stage the NEXT K-chunk's halo patch into the other LDS buffer meanwhile.
+// MFMA and VALU/VMEM are separate pipes per SIMD, so with one MFMA wave and one loader wave per SIMD the
+// staging cost disappears behind the 64-cycle v_mfma_f32_32x32x2_f32 issue interval.
 template <int WCO, int WPX, int TCO, int TPX>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
+__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  static_assert(WCO * WPX == 4, "4 waves per workgroup");
+  static_assert(WCO * WPX == 4, "4 MFMA waves per workgroup");
   constexpr int BCO_T = WCO * TCO;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wco = wave / WPX, wpx = wave % WPX;
-  const int h = lane >> 5, l31 = lane & 31;
+  const bool loader = wave >= 4;
   const ConvPtrs P = d.g[blockIdx.y];
+  const PatchGeom& pg = d.pg;
 
   int bid = blockIdx.x;
   const int cb = bid % d.ncb;
@@ -71,45 +115,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
   const int ty_i = pt % d.tiles_y;
   const int tn_i = pt / d.tiles_y;
   const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
-  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
-  const int rowmul = d.S * d.PWrow;
+  const int S_in = pg.S == 2 ? 2 : 1;
+  const int iyb = oy0 * S_in + d.iy0, ixb = ox0 * S_in + d.ix0;
+  const int bufsz = d.ckm * 8 * pg.CS;
+  const int nchunks = (d.nchunks8 + d.ckm - 1) / d.ckm;
 
-  // LDS offset of this lane's pixel (per 32-pixel tile), including the k-parity plane h
+  if (loader) {
+    const int ltid = tid - 256;
+    stage_patch(P.x, pg, 0, min(d.ckm, d.nchunks8) * 8, n0, iyb, ixb, smem, ltid, 256);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      if (chunk + 1 < nchunks) {
+        const int c8 = (chunk + 1) * d.ckm;
+        stage_patch(P.x, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, n0, iyb, ixb,
+                    smem + ((chunk + 1) & 1) * bufsz, ltid, 256);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ MFMA waves
+  const int wco = wave / WPX, wpx = wave % WPX;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+  const int rowmul = S_in * pg.PWrow;
   int boff[TPX];
 #pragma unroll
   for (int tp = 0; tp < TPX; ++tp) {
     const int p = (wpx * TPX + tp) * 32 + l31;
     const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
-    boff[tp] = h * d.CKS + ti * d.PP + ty * rowmul + tx;
+    boff[tp] = h * pg.CS + ti * pg.PP + ty * rowmul + tx;
   }
-
-  const int bufsz = 8 * d.CKS;
-  const int iyb = oy0 * d.S + d.iy0, ixb = ox0 * d.S + d.ix0;
-  const int PWp2m = (1 << d.lgPWp2) - 1;
-  const int total_e = (8 * (int)d.dTIPH.d) << d.lgPWp2;
-  const int HW = d.H * d.W;
-
-  auto stage = [&](int chunk, float* dst) {
-    for (int e = tid; e < total_e; e += 256) {
-      const int px = e & PWp2m;
-      const uint32_t r = (uint32_t)e >> d.lgPWp2;
-      if (px < d.PW) {
-        const uint32_t c8 = fdiv(r, d.dTIPH);
-        const uint32_t rem = r - c8 * d.dTIPH.d;
-        const uint32_t ti = fdiv(rem, d.dPH);
-        const uint32_t py = rem - ti * d.dPH.d;
-        const int c = chunk * 8 + (int)c8, n = n0 + (int)ti, iy = iyb + (int)py, ix = ixb + px;
-        float v = 0.0f;
-        if (c < d.Cin && n < d.N && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) {
-          v = P.x[(long long)n * d.x_bs + (long long)c * HW + iy * d.W + ix];
-          v = apply_act(v, d.pro_act);
-        }
-        const int col = (d.S == 2) ? ((px & 1) * d.PWh + (px >> 1)) : px;
-        dst[c8 * d.CKS + ti * d.PP + py * d.PWrow + col] = v;
-      }
-    }
-  };
-
   f32x16 acc[TCO][TPX];
 #pragma unroll
   for (int a = 0; a < TCO; ++a)
@@ -120,93 +157,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvDesc d) {
 
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(P.wp);
   const int cot0 = cb * BCO_T + wco * TCO;
-  int cot_ld[TCO];
+  int wl[TCO];  // per-lane fragment index of co tile a at Q = 0
 #pragma unroll
-  for (int a = 0; a < TCO; ++a) cot_ld[a] = min(cot0 + a, d.ncot - 1);
+  for (int a = 0; a < TCO; ++a) wl[a] = min(cot0 + a, d.ncot - 1) * 64 + lane;
+  const int qstride = d.ncot * 64;             // f32x4 elements between consecutive (chunk8, tap) steps
+  const int Qtot = d.nchunks8 * d.ntaps;
+  int Q = 0;
+  f32x4 a_nxt[TCO];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[wl[a]];
 
-  stage(0, smem);
-  __syncthreads();
-  for (int chunk = 0; chunk < d.nchunks; ++chunk) {
+  int toff_nxt = d.tapoff[0];
+  __syncthreads();  // patch of chunk 0 staged
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
     const float* cur = smem + (chunk & 1) * bufsz;
-    if (chunk + 1 < d.nchunks) stage(chunk + 1, smem + ((chunk + 1) & 1) * bufsz);
-    const long long wbase = (long long)chunk * d.ntaps * d.ncot;
-    f32x4 a_nxt[TCO];
+    const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
+    for (int sub = 0; sub < nsub; ++sub) {
+      const float* cb8 = cur + sub * 8 * pg.CS;
+      for (int t = 0; t < d.ntaps; ++t) {
+        f32x4 a_cur[TCO];
 #pragma unroll
-    for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(wbase + cot_ld[a]) * 64 + lane];
-    for (int t = 0; t < d.ntaps; ++t) {
-      f32x4 a_cur[TCO];
+        for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
+        ++Q;
+        if (Q < Qtot) {
 #pragma unroll
-      for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
-      if (t + 1 < d.ntaps) {
+          for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(long long)Q * qstride + wl[a]];
+        }
+        const float* bp = cb8 + toff_nxt;
+        toff_nxt = d.tapoff[t + 1 < d.ntaps ? t + 1 : 0];
+        float bv[4][TPX];
 #pragma unroll
-        for (int a = 0; a < TCO; ++a)
-          a_nxt[a] = wp4[(wbase + (long long)(t + 1) * d.ncot + cot_ld[a]) * 64 + lane];
-      }
-      const int toff = d.tapoff[t];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float bv[TPX];
+          for (int tp = 0; tp < TPX; ++tp) bv[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
 #pragma unroll
-        for (int tp = 0; tp < TPX; ++tp) bv[tp] = cur[boff[tp] + toff + 2 * j * d.CKS];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int a = 0; a < TCO; ++a)
+          for (int a = 0; a < TCO; ++a)
 #pragma unroll
-          for (int tp = 0; tp < TPX; ++tp)
-            acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[tp], acc[a][tp], 0, 0, 0);
+            for (int tp = 0; tp < TPX; ++tp)
+              acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[j][tp], acc[a][tp], 0, 0, 0);
       }
     }
     __syncthreads();
   }
 
   // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h
-  const long long plane = (long long)d.OHf * d.OWf;
 #pragma unroll
   for (int tp = 0; tp < TPX; ++tp) {
     const int p = (wpx * TPX + tp) * 32 + l31;
     const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
     const int n = n0 + ti, oyv = oy0 + ty, oxv = ox0 + tx;
-    const bool pvalid = (n < d.N) && (oyv < d.OHv) && (oxv < d.OWv);
+    const bool pvalid = (n < pg.N) && (oyv < d.OHv) && (oxv < d.OWv);
     const int oy = oyv * d.out_sy + d.out_oy, ox = oxv * d.out_sx + d.out_ox;
 #pragma unroll
     for (int a = 0; a < TCO; ++a) {
       const int cot = cot0 + a;
-      if (cot >= d.ncot) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (!pvalid || co >= d.Cout) continue;
-        long long pix;
-        if (d.ps2) {
-          pix = (long long)(co >> 2) * plane + (long long)(oy * 2 + ((co >> 1) & 1)) * d.OWf + ox * 2 + (co & 1);
-        } else {
-          pix = (long long)co * plane + (long long)oy * d.OWf + ox;
-        }
-        float v = acc[a][tp][r];
-        if (P.bias) v += P.bias[co];
-        switch (d.epi) {
-          case ICM_EPI_RES: v += P.res[n * d.res_bs + pix]; break;
-          case ICM_EPI_RES_GELU: v += gelu_f(P.res[n * d.res_bs + pix]); break;
-          case ICM_EPI_GDN: {
-            if (P.y2) P.y2[n * d.y2_bs + pix] = v;
-            v = P.aux[n * d.aux_bs + pix] * rsqrtf(v);
-          } break;
-          case ICM_EPI_IGDN: {
-            if (P.y2) P.y2[n * d.y2_bs + pix] = v;
-            v = P.aux[n * d.aux_bs + pix] * sqrtf(v);
-          } break;
-          case ICM_EPI_MUL_DGELU: v *= dgelu_f(P.aux[n * d.aux_bs + pix]); break;
-          case ICM_EPI_AXPY2: v = P.aux2[n * d.aux2_bs + pix] + 2.0f * P.aux[n * d.aux_bs + pix] * v; break;
-          case ICM_EPI_LRP: {
-            const float t = tanhf(v);
-            if (P.y2) P.y2[n * d.y2_bs + pix] = t;
-            v = P.aux[n * d.aux_bs + pix] + 0.5f * t;
-          } break;
-          default: break;
-        }
-        float* yp = P.y + n * d.y_bs + pix;
-        if (d.accum) v += *yp;
-        *yp = v;
-      }
+      if (cot < d.ncot) store_tile(d, P, acc[a][tp], cot, h, n, oy, ox, pvalid);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -315,10 +323,12 @@ struct KernelCfg {
   void (*fn)(const ConvDesc);
 };
 static const KernelCfg kCfgs[] = {
+    {1, 4, 3, 2, conv_igemm_kernel<1, 4, 3, 2>},  // 96 co x 256 px
+    {1, 4, 5, 2, conv_igemm_kernel<1, 4, 5, 2>},  // 160 x 256
     {1, 4, 2, 2, conv_igemm_kernel<1, 4, 2, 2>},  // 64 x 256
+    {1, 4, 1, 2, conv_igemm_kernel<1, 4, 1, 2>},  // 32 x 256
     {1, 4, 3, 1, conv_igemm_kernel<1, 4, 3, 1>},  // 96 x 128
     {1, 4, 5, 1, conv_igemm_kernel<1, 4, 5, 1>},  // 160 x 128
-    {1, 4, 1, 2, conv_igemm_kernel<1, 4, 1, 2>},  // 32 x 256
     {2, 2, 2, 1, conv_igemm_kernel<2, 2, 2, 1>},  // 128 x 64
     {2, 2, 1, 1, conv_igemm_kernel<2, 2, 1, 1>},  // 64 x 64
     {4, 1, 1, 1, conv_igemm_kernel<4, 1, 1, 1>},  // 128 x 32
@@ -327,11 +337,11 @@ static const KernelCfg kCfgs[] = {
 static int g_force_cfg = -1;
 
 struct Geometry {
-  int lgTW, lgTH, lgTI, PH, PW, PWh, PWrow, PP, CKS, tiles_x, tiles_y, tiles_n;
+  int lgTW, lgTH, lgTI, PH, PW, PWh, PWrow, PP, CS, tiles_x, tiles_y, tiles_n, ckm;
   size_t lds_bytes;
 };
 
-static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, int ex) {
+static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, int ex, int nchunks8, int ntaps) {
   Geometry g;
   const int lgB = ceil_log2(bpx);
   g.lgTW = std::min(std::min(5, lgB), ceil_log2(OWv));
@@ -343,11 +353,16 @@ static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, i
   g.PWh = (g.PW + 1) / 2;
   g.PWrow = (S == 2) ? 2 * g.PWh : g.PW;
   g.PP = g.PH * g.PWrow;
-  g.CKS = TI * g.PP;
+  g.CS = TI * g.PP;
   g.tiles_x = cdiv(OWv, TW);
   g.tiles_y = cdiv(OHv, TH);
   g.tiles_n = cdiv(N, TI);
-  g.lds_bytes = (size_t)2 * 8 * g.CKS * sizeof(float);
+  // channels per barrier: enough MFMA work per chunk to amortise it, within ~72 KB of LDS per buffer pair
+  int ckm = ntaps >= 16 ? 1 : (ntaps >= 4 ? 2 : 4);
+  ckm = std::min(ckm, nchunks8);
+  while (ckm > 1 && (size_t)2 * ckm * 8 * g.CS * sizeof(float) > 72 * 1024) ckm >>= 1;
+  g.ckm = ckm;
+  g.lds_bytes = (size_t)2 * ckm * 8 * g.CS * sizeof(float);
   return g;
 }
 
@@ -357,11 +372,13 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   const int OHv = a.transposed ? cdiv(a.OH - cls.cy, out_s) : a.OH;
   const int OWv = a.transposed ? cdiv(a.OW - cls.cx, out_s) : a.OW;
   if (OHv <= 0 || OWv <= 0) return ICM_OK;
-  const int ncot = cdiv(a.Cout, 32), nchunks = cdiv(a.Cin, 8);
+  const int ncot = cdiv(a.Cout, 32), nchunks8 = cdiv(a.Cin, 8);
   const int ntaps = (int)cls.taps.size();
   if (ntaps > ICM_MAX_TAPS) return ICM_ERR_UNSUPPORTED;
 
-  // pick the tile configuration: minimise (waves of workgroups) x (MFMA work per workgroup)
+  // pick the tile configuration: time ~ ceil(workgroups / 256 CUs) x (MFMAs per MFMA wave) / efficiency, with the
+  // per-configuration efficiency measured on MI355X (tools/tune_conv.py; profiles/r01_tune_conv.txt)
+  static const double kEff[] = {0.80, 0.42, 0.76, 0.52, 1.00, 0.62, 0.84, 0.90, 0.86, 0.74};
   int best = -1;
   double best_cost = 1e300;
   Geometry bg{};
@@ -370,20 +387,12 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     if (g_force_cfg >= 0 && i != g_force_cfg) continue;
     const KernelCfg& c = kCfgs[i];
     const int bpx = c.wpx * c.tpx * 32, bco_t = c.wco * c.tco;
-    Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex);
-    if (g.lds_bytes > 64 * 1024 && g_force_cfg < 0) {
-      if (g.lds_bytes > 160 * 1024) continue;
-    }
+    Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps);
     if (g.lds_bytes > 160 * 1024) continue;
     const long long blocks = (long long)cdiv(ncot, bco_t) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
-    const int acc_regs = c.tco * c.tpx * 16;
-    int occ = acc_regs <= 48 ? 3 : (acc_regs <= 96 ? 2 : 1);
-    occ = std::min<long long>(occ, std::max<size_t>(1, (size_t)(160 * 1024) / std::max<size_t>(g.lds_bytes, 1)));
-    const double rounds = (double)cdiv((int)std::min<long long>(blocks, 1 << 30), 256 * occ);
-    // per-workgroup time ~ MFMAs per wave (64 cycles each), inflated when a wave has little register reuse
-    const double mfma = (double)c.tco * c.tpx * nchunks * ntaps * 4;
-    const double reuse_pen = 1.0 + 0.35 / (c.tco * c.tpx);
-    const double cost = rounds * occ * mfma * reuse_pen + rounds * 200.0;
+    const double per_cu = (double)((blocks + 255) / 256);
+    const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4;   // per MFMA wave
+    const double cost = per_cu * mfma / kEff[i] + per_cu * 200.0;
     if (cost < best_cost) {
       best_cost = cost;
       best = i;
@@ -405,29 +414,32 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     d.g[gi].aux2 = s.aux2;
     d.g[gi].y2 = s.y2;
   }
-  d.x_bs = a.x_bs; d.y_bs = a.y_bs; d.res_bs = a.res_bs; d.aux_bs = a.aux_bs; d.aux2_bs = a.aux2_bs; d.y2_bs = a.y2_bs;
-  d.N = a.N; d.Cin = a.Cin; d.H = a.H; d.W = a.W; d.Cout = a.Cout;
+  d.y_bs = a.y_bs; d.res_bs = a.res_bs; d.aux_bs = a.aux_bs; d.aux2_bs = a.aux2_bs; d.y2_bs = a.y2_bs;
+  PatchGeom& pg = d.pg;
+  pg.PW = bg.PW; pg.PH = bg.PH; pg.PWrow = bg.PWrow; pg.PWh = bg.PWh; pg.PP = bg.PP; pg.CS = bg.CS; pg.S = S_in;
+  pg.TIPH = (1 << bg.lgTI) * bg.PH;
+  pg.dPW = make_fastdiv((uint32_t)bg.PW);
+  pg.dTIPH = make_fastdiv((uint32_t)pg.TIPH);
+  pg.dPH = make_fastdiv((uint32_t)bg.PH);
+  pg.H = a.H; pg.W = a.W; pg.N = a.N; pg.C = a.Cin; pg.act = a.pro_act; pg.bs = a.x_bs;
+  d.Cout = a.Cout;
   d.ps2 = a.pixel_shuffle == 2;
   d.OHf = d.ps2 ? a.OH * 2 : a.OH;
   d.OWf = d.ps2 ? a.OW * 2 : a.OW;
   d.OHv = OHv; d.OWv = OWv;
   d.out_sy = d.out_sx = out_s;
   d.out_oy = cls.cy; d.out_ox = cls.cx;
-  d.iy0 = cls.iy0; d.ix0 = cls.ix0; d.S = S_in;
+  d.iy0 = cls.iy0; d.ix0 = cls.ix0;
   d.ntaps = ntaps;
   d.lgTW = bg.lgTW; d.lgTH = bg.lgTH; d.lgTI = bg.lgTI;
-  d.PH = bg.PH; d.PW = bg.PW; d.PWh = bg.PWh; d.PWrow = bg.PWrow; d.PP = bg.PP; d.CKS = bg.CKS;
-  d.lgPWp2 = ceil_log2(bg.PW);
-  d.dTIPH = make_fastdiv((uint32_t)((1 << bg.lgTI) * bg.PH));
-  d.dPH = make_fastdiv((uint32_t)bg.PH);
   d.tiles_x = bg.tiles_x; d.tiles_y = bg.tiles_y; d.tiles_n = bg.tiles_n;
-  d.ncot = ncot; d.nchunks = nchunks; d.ncb = cdiv(ncot, c.wco * c.tco);
-  d.pro_act = a.pro_act; d.epi = a.epi; d.accum = a.accum;
+  d.ncot = ncot; d.nchunks8 = nchunks8; d.ckm = bg.ckm; d.ncb = cdiv(ncot, c.wco * c.tco);
+  d.epi = a.epi; d.accum = a.accum;
   for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapoff[t] = 0;
   for (int t = 0; t < ntaps; ++t) {
     const Tap& tp = cls.taps[t];
     const int col = (S_in == 2) ? ((tp.dx & 1) * bg.PWh + (tp.dx >> 1)) : tp.dx;
-    d.tapoff[t] = (short)(tp.dy * bg.PWrow + col);
+    d.tapoff[t] = tp.dy * bg.PWrow + col;
   }
   const long long nblk = (long long)d.ncb * d.tiles_x * d.tiles_y * d.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
@@ -435,7 +447,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)bg.lds_bytes);
   }
-  hipLaunchKernelGGL(c.fn, dim3((unsigned)nblk, ngroups, 1), dim3(256), bg.lds_bytes, stream, d);
+  hipLaunchKernelGGL(c.fn, dim3((unsigned)nblk, ngroups, 1), dim3(512), bg.lds_bytes, stream, d);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

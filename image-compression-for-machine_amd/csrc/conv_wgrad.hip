@@ -1,14 +1,17 @@
 // Weight-gradient kernel of the convolution family (f32 MFMA, gfx950).
 //
-//   dW[a][b][t] = sum_{n,p} actS(gs[n,a,p]) * actB(gb[n,b,p*stride - pad + t])
+//   dW[a][b][t] = sum_{n,p} actS(gs[n,a,p]) * actB(gb[n,b,p*stride - pad + t])        (+ optional db[a] = sum gs)
 //
-// GEMM view: M = a (channels of the small-grid tensor), N = b (channels of the big-grid tensor),
-// K = pixels.  Per workgroup: 128 a x (32*TB) b x NT taps, accumulated over its share of the pixel
-// tiles (64 small-grid pixels each).  Both operands are staged once per pixel tile into LDS -- the
-// small-grid tile as [a][pixel] (row stride 65: conflict-free A fragments), the big-grid halo patch
-// as [b][patch] (odd plane stride: conflict-free B fragments) -- and the patch is re-read for every
-// tap.  Pixel-split partial sums go to [split][tap][a][b] slabs with 128-B coalesced plain stores and
-// are reduced by a second kernel: bitwise reproducible, no float atomics (Guideline 12).
+// GEMM view: M = a (channels of the small-grid tensor), N = b (channels of the big-grid tensor), K = pixels.
+// Workgroup = 512 threads: 4 MFMA waves + 4 loader waves (same split as conv_igemm.hip).  Per pixel tile
+// (64 small-grid pixels) the loaders stage the small-grid tile as [a][pixel] (row stride 65: conflict-free A
+// fragments) and the big-grid halo patch as [b][patch] (odd plane stride: conflict-free B fragments) into the
+// other LDS buffer while the MFMA waves sweep the current one: every (tap, b-tile) pair re-reads the same
+// patch at a different offset, so one staging serves up to 16 taps.  Accumulators ([TA a-tiles] x [pairs of
+// this wave]) stay in registers across the workgroup's whole share of the pixel tiles; partial sums go to
+// [split][tap][a][b] slabs with 128-B coalesced plain stores and are reduced + transposed to the canonical
+// [a][b][kh][kw] layout by a second kernel: bitwise reproducible, no float atomics (Guideline 12).
+// The bias gradient (row sums of the small-grid tile) is accumulated by the loader waves for free.
 #include <algorithm>
 #include "icm_common.h"
 
@@ -20,150 +23,200 @@ struct WgDesc {
   const float* gs;
   const float* gb;
   float* ws;
-  long long gs_bs, gb_bs;
-  int Ca, OH, OW, Cb, H, W, N;
-  int S, pad, ntaps, act_s, act_b;
-  int lgTW, lgTH, lgTI, PH, PW, PPimg, PPo, lgPWp2;
-  FastDiv dTIPH, dPH;
+  float* dbias_ws;   // [nsplit][Ca] or null
+  long long gs_bs;
+  PatchGeom pg;      // big-grid tensor + patch layout (identity colmap)
+  int Ca, OH, OW, act_s;
+  int S, pad, ntaps, tpg;   // taps per tap-group
+  int lgTW, lgTH, lgTI, lgNPX;
   int tiles_x, tiles_y, tiles_n, ntiles, nsplit;
   int natile, nbtile, ngroups;
-  short tapoff[WG_MAX_TAPS];
+  int tapoff[WG_MAX_TAPS];
 };
 
-template <int NT, int TB>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgDesc d) {
+template <int TA, int TB, int NP>
+__global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* gsT = smem;                       // [128][65]
-  float* gbP = smem + 128 * 65;            // [32*TB][PPo]
-  int* poff = reinterpret_cast<int*>(gbP + 32 * TB * d.PPo);  // [64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  constexpr int NACC = TA * NP;
+  const PatchGeom& pg = d.pg;
+  const int npx = 1 << d.lgNPX, grow = npx + 1;   // pixels per tile (16/32/64), gs row stride
+  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
+  const int bufsz = gs_sz + gb_sz;
+  int* poff = reinterpret_cast<int*>(smem + 2 * bufsz);  // [npx]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
 
   int bid = blockIdx.x;
   const int at = bid % d.natile; bid /= d.natile;
   const int bt = bid % d.nbtile; bid /= d.nbtile;
   const int tg = bid % d.ngroups;
   const int split = bid / d.ngroups;
-  const int a0 = at * 128, b0 = bt * 32 * TB, t0 = tg * NT;
-  const int nt = min(NT, d.ntaps - t0);
+  const int a0 = at * TA * 32, b0 = bt * TB * 32, t0 = tg * d.tpg;
+  const int nt = min(d.tpg, d.ntaps - t0);
   const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+  const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
 
-  if (tid < 64) {
+  if (tid < npx) {
     const int tx = tid & TWm, ty = (tid >> d.lgTW) & THm, ti = tid >> (d.lgTW + d.lgTH);
-    poff[tid] = ti * d.PPimg + ty * d.S * d.PW + tx * d.S;
+    poff[tid] = ti * pg.PP + ty * d.S * pg.PW + tx * d.S;
   }
-  int toff[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) toff[t] = d.tapoff[min(t0 + t, d.ntaps - 1)];
 
-  f32x16 acc[NT][TB];
+  if (loader) {
+    const int ltid = tid - 256;
+    const bool do_bias = d.dbias_ws != nullptr && bt == 0 && tg == 0;
+    float bsum[TA * 8];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int k = 0; k < TA * 8; ++k) bsum[k] = 0.0f;
+    const int OHW = d.OH * d.OW;
+    const int p = ltid & (npx - 1), a_sub = ltid >> d.lgNPX, a_step = 256 >> d.lgNPX;
+    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
+    for (int it = 0; it <= niter; ++it) {
+      if (it < niter) {
+        int q = split + it * d.nsplit;
+        const int tx_i = q % d.tiles_x; q /= d.tiles_x;
+        const int ty_i = q % d.tiles_y;
+        const int tn_i = q / d.tiles_y;
+        const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
+        float* gsT = smem + (it & 1) * bufsz;
+        float* gbP = gsT + gs_sz;
+        const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
+        const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
+        const float* src = d.gs + (long long)n * d.gs_bs + oy * d.OW + ox;
 #pragma unroll
-    for (int b = 0; b < TB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][b][r] = 0.0f;
-
-  const int OHW = d.OH * d.OW, HW = d.H * d.W;
-  const int PWp2m = (1 << d.lgPWp2) - 1;
-  const int total_e = (32 * TB * (int)d.dTIPH.d) << d.lgPWp2;
-
-  for (int tile = split; tile < d.ntiles; tile += d.nsplit) {
-    int q = tile;
-    const int tx_i = q % d.tiles_x; q /= d.tiles_x;
-    const int ty_i = q % d.tiles_y;
-    const int tn_i = q / d.tiles_y;
-    const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
-    __syncthreads();
-    // small-grid tile: 128 channels x 64 pixels
-    for (int e = tid; e < 128 * 64; e += 256) {
-      const int p = e & 63, a = e >> 6;
-      const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
-      const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx, ca = a0 + a;
-      float v = 0.0f;
-      if (ca < d.Ca && n < d.N && oy < d.OH && ox < d.OW) {
-        v = d.gs[(long long)n * d.gs_bs + (long long)ca * OHW + oy * d.OW + ox];
-        v = apply_act(v, d.act_s);
-      }
-      gsT[a * 65 + p] = v;
-    }
-    // big-grid halo patch: 32*TB channels
-    const int iyb = oy0 * d.S - d.pad, ixb = ox0 * d.S - d.pad;
-    for (int e = tid; e < total_e; e += 256) {
-      const int px = e & PWp2m;
-      const uint32_t r = (uint32_t)e >> d.lgPWp2;
-      if (px < d.PW) {
-        const uint32_t cb = fdiv(r, d.dTIPH);
-        const uint32_t rem = r - cb * d.dTIPH.d;
-        const uint32_t ti = fdiv(rem, d.dPH);
-        const uint32_t py = rem - ti * d.dPH.d;
-        const int c = b0 + (int)cb, n = n0 + (int)ti, iy = iyb + (int)py, ix = ixb + px;
-        float v = 0.0f;
-        if (c < d.Cb && n < d.N && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) {
-          v = d.gb[(long long)n * d.gb_bs + (long long)c * HW + iy * d.W + ix];
-          v = apply_act(v, d.act_b);
-        }
-        gbP[cb * d.PPo + ti * d.PPimg + py * d.PW + px] = v;
-      }
-    }
-    __syncthreads();
-    const float* arow = gsT + (wave * 32 + l31) * 65 + h;
-#pragma unroll 2
-    for (int kp = 0; kp < 32; ++kp) {
-      const int po = poff[2 * kp + h];
-      const float av = arow[2 * kp];
-#pragma unroll
-      for (int tb = 0; tb < TB; ++tb) {
-        const float* bp = gbP + (tb * 32 + l31) * d.PPo + po;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t < nt) {
-            const float bv = bp[toff[t]];
-            acc[t][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][tb], 0, 0, 0);
+        for (int k = 0; k < TA * 8; ++k) {
+          const int a = a_sub + a_step * k, ca = a0 + a;
+          if (a < TA * 32) {
+            float v = 0.0f;
+            if (pv && ca < d.Ca) {
+              v = src[(long long)ca * OHW];
+              v = apply_act(v, d.act_s);
+            }
+            gsT[a * grow + p] = v;
+            bsum[k] += v;
           }
         }
+        stage_patch_u<16>(d.gb, pg, b0, TB * 32, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, gbP, ltid, 256);
+      }
+      __syncthreads();
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int k = 0; k < TA * 8; ++k) {
+        float s = bsum[k];
+        for (int o = 32; o > 0; o >>= 1)
+          if (o < npx) s += __shfl_xor(s, o, 64);   // lanes sharing a channel are npx consecutive lanes
+        const int a = a_sub + a_step * k, ca = a0 + a;
+        if (p == 0 && a < TA * 32 && ca < d.Ca) d.dbias_ws[(long long)split * d.Ca + ca] = s;
       }
     }
+    return;
+  }
+
+  // ------------------------------------------------------------------ MFMA waves
+  const int h = lane >> 5, l31 = lane & 31;
+  // pair m of this wave: q = wave + 4*m -> (tap = q / TB, tb = q % TB); invalid pairs repeat pair 0 and are not stored
+  int boffs[NP];
+  bool pvalid[NP];
+#pragma unroll
+  for (int m = 0; m < NP; ++m) {
+    const int q = wave + 4 * m;
+    pvalid[m] = q < nt * TB;
+    const int qq = pvalid[m] ? q : 0;
+    const int tap = qq / TB, tb = qq % TB;
+    boffs[m] = (tb * 32 + l31) * pg.CS + d.tapoff[t0 + tap];
+  }
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  __syncthreads();  // tile 0 staged
+  for (int it = 0; it < niter; ++it) {
+    const float* gsT = smem + (it & 1) * bufsz;
+    const float* gbP = gsT + gs_sz;
+    const float* arow = gsT + l31 * grow + h;
+    const int nkp = npx >> 1;
+#pragma unroll 2
+    for (int kp = 0; kp < nkp; ++kp) {
+      const int po = poff[2 * kp + h];
+      float av[TA];
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta) av[ta] = arow[ta * 32 * grow + 2 * kp];
+#pragma unroll
+      for (int m = 0; m < NP; ++m) {
+        if (pvalid[m]) {
+          const float bv = gbP[boffs[m] + po];
+#pragma unroll
+          for (int ta = 0; ta < TA; ++ta)
+            acc[m * TA + ta] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv, acc[m * TA + ta], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
   }
 
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t >= nt) continue;
+  for (int m = 0; m < NP; ++m) {
+    if (!pvalid[m]) continue;
+    const int q = wave + 4 * m;
+    const int tap = t0 + q / TB, tb = q % TB;
+    const int b = b0 + tb * 32 + l31;
 #pragma unroll
-    for (int tb = 0; tb < TB; ++tb) {
-      const int b = b0 + tb * 32 + l31;
+    for (int ta = 0; ta < TA; ++ta) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int a = a0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (a < d.Ca && b < d.Cb)
-          d.ws[(((long long)split * d.ntaps + t0 + t) * d.Ca + a) * d.Cb + b] = acc[t][tb][r];
+        const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (a < d.Ca && b < pg.C)
+          d.ws[(((long long)split * d.ntaps + tap) * d.Ca + a) * pg.C + b] = acc[m * TA + ta][r];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // dw[(a*Cb + b)*ntaps + t] (+)= sum_s ws[((s*ntaps + t)*Ca + a)*Cb + b]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Ca, int Cb,
-                                    int ntaps, int nsplit, int accum) {
-  const long long total = (long long)Ca * Cb * ntaps;
-  const long long slab = total;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    // i enumerates (t, a, b) with b fastest: coalesced slab reads
-    const int b = (int)(i % Cb);
-    const long long q = i / Cb;
-    const int a = (int)(q % Ca);
-    const int t = (int)(q / Ca);
+// workgroup = one a, 32 consecutive b: reads 128-B rows per tap, transposes through LDS, writes ntaps*32
+// contiguous floats of the canonical layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int Ca, int Cb, int ntaps, int nsplit, int accum) {
+  __shared__ float tile[WG_MAX_TAPS][33];
+  const int nbt = (Cb + 31) / 32;
+  const int a = blockIdx.x / nbt, b0 = (blockIdx.x % nbt) * 32;
+  const long long slab = (long long)Ca * Cb * ntaps;
+  for (int e = threadIdx.x; e < ntaps * 32; e += 256) {
+    const int t = e >> 5, bl = e & 31;
     float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += ws[k * slab + i];
-    float* o = dw + ((long long)a * Cb + b) * ntaps + t;
-    if (accum) s += *o;
-    *o = s;
+    if (b0 + bl < Cb) {
+      const long long idx = ((long long)t * Ca + a) * Cb + b0 + bl;
+      for (int k = 0; k < nsplit; ++k) s += ws[k * slab + idx];
+    }
+    tile[t][bl] = s;
+  }
+  __syncthreads();
+  const int nb = min(32, Cb - b0);
+  float* o = dw + ((long long)a * Cb + b0) * ntaps;
+  for (int e = threadIdx.x; e < nb * ntaps; e += 256) {
+    const int bl = e / ntaps, t = e - bl * ntaps;
+    float v = tile[t][bl];
+    if (accum) v += o[e];
+    o[e] = v;
   }
 }
 
+__global__ void bias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int Ca, int nsplit,
+                                   int accum) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= Ca) return;
+  float s = 0.0f;
+  for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * Ca + a];
+  if (accum) s += db[a];
+  db[a] = s;
+}
+
 struct WgPlan {
-  int nt, tb;        // kernel variant
-  int lgTW, lgTH, lgTI, PH, PW, PPimg, PPo;
+  int ta, tb, np, tpg;
+  int lgTW, lgTH, lgTI, lgNPX, PH, PW, PP, CS;
   int tiles_x, tiles_y, tiles_n, ntiles, nsplit, natile, nbtile, ngroups;
   size_t lds;
 };
@@ -174,25 +227,36 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p) {
   if (a.OH != (a.H + 2 * a.pad - a.KH) / a.stride + 1 || a.OW != (a.W + 2 * a.pad - a.KW) / a.stride + 1)
     return ICM_ERR_ARG;
   const int ntaps = a.KH * a.KW;
-  if (ntaps == 1) { p.nt = 1; p.tb = 4; }
-  else if (ntaps <= 9) { p.nt = 9; p.tb = 1; }
-  else { p.nt = 5; p.tb = 1; }
-  p.lgTW = std::min(4, ceil_log2(a.OW));
-  p.lgTH = std::min(6 - p.lgTW, ceil_log2(a.OH));
-  p.lgTI = 6 - p.lgTW - p.lgTH;
+  bool ok = false;
+  for (int lg = 6; lg >= 4 && !ok; --lg) {   // pixels per tile: 64, else 32 / 16 for tiny images with big halos
+    p.lgNPX = lg;
+    p.lgTW = std::min(std::min(4, lg), ceil_log2(a.OW));
+    p.lgTH = std::min(lg - p.lgTW, ceil_log2(a.OH));
+    p.lgTI = lg - p.lgTW - p.lgTH;
+    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TI = 1 << p.lgTI;
+    p.PW = (TW - 1) * a.stride + a.KW;
+    p.PH = (TH - 1) * a.stride + a.KH;
+    p.PP = p.PH * p.PW;
+    p.CS = TI * p.PP;
+    if ((p.CS & 1) == 0) p.CS += 1;
+    auto lds_of = [&](int ta, int tb) {
+      return (size_t)2 * (ta * 32 * ((1 << lg) + 1) + tb * 32 * p.CS) * 4 + (size_t)(1 << lg) * 4;
+    };
+    if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) { p.ta = 4; p.tb = 4; p.np = 1; p.tpg = 1; ok = true; }
+    else if (ntaps <= 10 && lds_of(2, 2) <= 150 * 1024) { p.ta = 2; p.tb = 2; p.np = 5; p.tpg = ntaps; ok = true; }
+    else if (lds_of(2, 1) <= 150 * 1024) {
+      p.ta = 2; p.tb = 1; p.np = 4; p.tpg = ntaps <= 16 ? ntaps : (ntaps + 1) / 2; ok = true;
+    }
+    if (ok) p.lds = lds_of(p.ta, p.tb);
+  }
+  if (!ok) return ICM_ERR_UNSUPPORTED;
   const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TI = 1 << p.lgTI;
-  p.PW = (TW - 1) * a.stride + a.KW;
-  p.PH = (TH - 1) * a.stride + a.KH;
-  p.PPimg = p.PH * p.PW;
-  p.PPo = TI * p.PPimg;
-  if ((p.PPo & 1) == 0) p.PPo += 1;
   p.tiles_x = cdiv(a.OW, TW); p.tiles_y = cdiv(a.OH, TH); p.tiles_n = cdiv(a.N, TI);
   p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
-  p.natile = cdiv(a.Ca, 128); p.nbtile = cdiv(a.Cb, 32 * p.tb); p.ngroups = cdiv(ntaps, p.nt);
+  p.natile = cdiv(a.Ca, 32 * p.ta); p.nbtile = cdiv(a.Cb, 32 * p.tb); p.ngroups = cdiv(ntaps, p.tpg);
   const int base = p.natile * p.nbtile * p.ngroups;
-  p.nsplit = std::max(1, std::min(p.ntiles, cdiv(1024, base)));
-  p.lds = (size_t)(128 * 65 + 32 * p.tb * p.PPo) * 4 + 64 * 4;
-  if (p.lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
+  // ~3 workgroups per CU in flight; small problems get one pixel tile per workgroup (latency over reuse)
+  p.nsplit = std::max(1, std::min(p.ntiles, cdiv(768, base)));
   return ICM_OK;
 }
 
@@ -203,7 +267,7 @@ extern "C" {
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a) {
   icm::WgPlan p;
   if (!a || icm::plan_wgrad(*a, p)) return -1;
-  return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb;
+  return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
 }
 
 int icm_conv_wgrad(const icm_wgrad_args* a, void* stream_) {
@@ -213,33 +277,44 @@ int icm_conv_wgrad(const icm_wgrad_args* a, void* stream_) {
   int rc = plan_wgrad(*a, p);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  const int ntaps = a->KH * a->KW;
   WgDesc d;
-  d.gs = a->gs; d.gb = a->gb; d.ws = a->ws; d.gs_bs = a->gs_bs; d.gb_bs = a->gb_bs;
-  d.Ca = a->Ca; d.OH = a->OH; d.OW = a->OW; d.Cb = a->Cb; d.H = a->H; d.W = a->W; d.N = a->N;
-  d.S = a->stride; d.pad = a->pad; d.ntaps = a->KH * a->KW; d.act_s = a->act_s; d.act_b = a->act_b;
-  d.lgTW = p.lgTW; d.lgTH = p.lgTH; d.lgTI = p.lgTI; d.PH = p.PH; d.PW = p.PW; d.PPimg = p.PPimg; d.PPo = p.PPo;
-  d.lgPWp2 = ceil_log2(p.PW);
-  d.dTIPH = make_fastdiv((uint32_t)((1 << p.lgTI) * p.PH));
-  d.dPH = make_fastdiv((uint32_t)p.PH);
+  d.gs = a->gs; d.gb = a->gb; d.ws = a->ws; d.gs_bs = a->gs_bs;
+  const long long slab_all = (long long)p.nsplit * ntaps * a->Ca * a->Cb;
+  d.dbias_ws = a->dbias ? a->ws + slab_all : nullptr;
+  PatchGeom& pg = d.pg;
+  pg.PW = p.PW; pg.PH = p.PH; pg.PWrow = p.PW; pg.PWh = 0; pg.PP = p.PP; pg.CS = p.CS; pg.S = 1;
+  pg.TIPH = (1 << p.lgTI) * p.PH;
+  pg.dPW = make_fastdiv((uint32_t)p.PW);
+  pg.dTIPH = make_fastdiv((uint32_t)pg.TIPH);
+  pg.dPH = make_fastdiv((uint32_t)p.PH);
+  pg.H = a->H; pg.W = a->W; pg.N = a->N; pg.C = a->Cb; pg.act = a->act_b; pg.bs = a->gb_bs;
+  d.Ca = a->Ca; d.OH = a->OH; d.OW = a->OW; d.act_s = a->act_s;
+  d.S = a->stride; d.pad = a->pad; d.ntaps = ntaps; d.tpg = p.tpg;
+  d.lgTW = p.lgTW; d.lgTH = p.lgTH; d.lgTI = p.lgTI; d.lgNPX = p.lgNPX;
   d.tiles_x = p.tiles_x; d.tiles_y = p.tiles_y; d.tiles_n = p.tiles_n; d.ntiles = p.ntiles; d.nsplit = p.nsplit;
   d.natile = p.natile; d.nbtile = p.nbtile; d.ngroups = p.ngroups;
   for (int t = 0; t < WG_MAX_TAPS; ++t) d.tapoff[t] = 0;
   for (int kh = 0; kh < a->KH; ++kh)
-    for (int kw = 0; kw < a->KW; ++kw) d.tapoff[kh * a->KW + kw] = (short)(kh * p.PW + kw);
+    for (int kw = 0; kw < a->KW; ++kw) d.tapoff[kh * a->KW + kw] = kh * p.PW + kw;
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.nt == 1 && p.tb == 4) fn = wgrad_kernel<1, 4>;
-  else if (p.nt == 9) fn = wgrad_kernel<9, 1>;
-  else fn = wgrad_kernel<5, 1>;
+  if (p.ta == 4) fn = wgrad_kernel<4, 4, 1>;
+  else if (p.tb == 2) fn = wgrad_kernel<2, 2, 5>;
+  else fn = wgrad_kernel<2, 1, 4>;
   if (p.lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(256), p.lds, stream, d);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), p.lds, stream, d);
   ICM_CHECK_LAUNCH();
-  const long long total = (long long)a->Ca * a->Cb * d.ntaps;
-  const int rblocks = (int)std::min<long long>((total + 255) / 256, 2048);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, a->ws, a->dw, a->Ca, a->Cb,
-                     d.ntaps, p.nsplit, a->accum);
+  const int rblocks = a->Ca * cdiv(a->Cb, 32);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, a->ws, a->dw, a->Ca, a->Cb, ntaps,
+                     p.nsplit, a->accum);
   ICM_CHECK_LAUNCH();
+  if (a->dbias) {
+    hipLaunchKernelGGL(bias_reduce_kernel, dim3(cdiv(a->Ca, 256)), dim3(256), 0, stream, d.dbias_ws, a->dbias, a->Ca,
+                       p.nsplit, a->accum_bias);
+    ICM_CHECK_LAUNCH();
+  }
   return ICM_OK;
 }
 

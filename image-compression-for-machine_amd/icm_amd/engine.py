@@ -129,7 +129,8 @@ def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transpo
     check(L.lib().icm_conv_run(C.byref(a), tape.st), "conv_run")
 
 
-def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0):
+def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
+                 dbias=None, accum_bias=0):
     a = L.WgradArgs()
     N, _, OH, OW = gs.shape
     _, _, H, W = gb.shape
@@ -137,6 +138,7 @@ def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NON
     a.gb, a.gb_bs, a.Cb, a.H, a.W, a.act_b = ptr(gb), bs(gb), Cb, H, W, act_b
     a.N, a.KH, a.KW, a.stride, a.pad = N, KH, KW, stride, pad
     a.dw, a.accum = ptr(dw), accum
+    a.dbias, a.accum_bias = ptr(dbias), accum_bias
     a.ws = 0
     n = L.lib().icm_wgrad_workspace_floats(C.byref(a))
     if n < 0:
@@ -222,14 +224,17 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             dy = du
         if res is not None:
             accumulate(tape, res.t, dy, res.t if res.act == ACT_GELU else None)
-        if b is not None and tape.wants(b):
+        want_b = b is not None and tape.wants(b)
+        fuse_b = want_b and not transposed and tape.wants(w)   # bias grad rides on the wgrad loaders
+        if want_b and not fuse_b:
             gb_, acc = tape.grad_for_write(b)
             check(L.lib().icm_channel_sum(ptr(dy), bs(dy), N, Cout, OH * OW, ptr(gb_), acc, tape.st), "channel_sum")
         if tape.wants(w):
             gw, acc = tape.grad_for_write(w)
             if not transposed:
+                gb_, accb = tape.grad_for_write(b) if fuse_b else (None, 0)
                 wgrad_launch(tape, dy, x, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=act,
-                             accum=acc)
+                             accum=acc, dbias=gb_, accum_bias=accb)
             else:
                 wgrad_launch(tape, x, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=act,
                              accum=acc)

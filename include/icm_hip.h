@@ -99,6 +99,7 @@ typedef struct icm_wgrad_args {
   const float* gb; int64_t gb_bs; int Cb, H, W; int act_b;
   int N, KH, KW, stride, pad;
   float* dw; float* ws; int accum;
+  float* dbias; int accum_bias;   /* optional: dbias[a] (+)= sum_{n,p} actS(gs[n,a,p]) (conv bias gradient, fused) */
 } icm_wgrad_args;
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a);
 int icm_conv_wgrad(const icm_wgrad_args* a, void* stream);

@@ -38,7 +38,7 @@ def test_host_planning_entry_points():
     a.KH = a.KW = 5
     a.stride, a.pad = 2, 2
     n = L.icm_wgrad_workspace_floats(ctypes.byref(a))
-    assert n > 0 and n % (25 * 192 * 192) == 0
+    assert n > 0 and n % 192 == 0
     a.OH = 63  # inconsistent geometry -> rejected like a shape error
     assert L.icm_wgrad_workspace_floats(ctypes.byref(a)) == -1
     # argument validation happens before any launch: NULL pointers / bad stride are refused on CPU too
