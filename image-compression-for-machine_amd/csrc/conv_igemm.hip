@@ -121,14 +121,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
   const int nchunks = (d.nchunks8 + d.ckm - 1) / d.ckm;
 
   if (loader) {
-    const int ltid = tid - 256;
-    stage_patch(P.x, pg, 0, min(d.ckm, d.nchunks8) * 8, n0, iyb, ixb, smem, ltid, 256);
+    const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
+    PlaneMap pm;
+    plane_map_init(pm, pg, n0, iyb, ixb, lane);
+    stage_planes(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       if (chunk + 1 < nchunks) {
         const int c8 = (chunk + 1) * d.ckm;
-        stage_patch(P.x, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, n0, iyb, ixb,
-                    smem + ((chunk + 1) & 1) * bufsz, ltid, 256);
+        stage_planes(P.x, pm, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, smem + ((chunk + 1) & 1) * bufsz, lw);
       }
       __syncthreads();
     }
@@ -324,7 +325,7 @@ struct KernelCfg {
 };
 static const KernelCfg kCfgs[] = {
     {1, 4, 3, 2, conv_igemm_kernel<1, 4, 3, 2>},  // 96 co x 256 px
-    {1, 4, 5, 2, conv_igemm_kernel<1, 4, 5, 2>},  // 160 x 256
+    {1, 4, 6, 1, conv_igemm_kernel<1, 4, 6, 1>},  // 192 x 128
     {1, 4, 2, 2, conv_igemm_kernel<1, 4, 2, 2>},  // 64 x 256
     {1, 4, 1, 2, conv_igemm_kernel<1, 4, 1, 2>},  // 32 x 256
     {1, 4, 3, 1, conv_igemm_kernel<1, 4, 3, 1>},  // 96 x 128
@@ -341,7 +342,8 @@ struct Geometry {
   size_t lds_bytes;
 };
 
-static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, int ex, int nchunks8, int ntaps) {
+static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, int ex, int nchunks8, int ntaps,
+                              int tiles_per_wave) {
   Geometry g;
   const int lgB = ceil_log2(bpx);
   g.lgTW = std::min(std::min(5, lgB), ceil_log2(OWv));
@@ -357,10 +359,11 @@ static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, i
   g.tiles_x = cdiv(OWv, TW);
   g.tiles_y = cdiv(OHv, TH);
   g.tiles_n = cdiv(N, TI);
-  // channels per barrier: enough MFMA work per chunk to amortise it, within ~72 KB of LDS per buffer pair
-  int ckm = ntaps >= 16 ? 1 : (ntaps >= 4 ? 2 : 4);
-  ckm = std::min(ckm, nchunks8);
-  while (ckm > 1 && (size_t)2 * ckm * 8 * g.CS * sizeof(float) > 72 * 1024) ckm >>= 1;
+  // channels per barrier: >= ~256 MFMAs per MFMA wave between barriers (16k cycles) so that the loaders' L2/HBM
+  // round trips and the barrier itself stay hidden, within 64 KB of LDS for the two buffers
+  int ckm = cdiv(256, ntaps * 4 * tiles_per_wave);
+  ckm = std::max(1, std::min(ckm, nchunks8));
+  while (ckm > 1 && (size_t)2 * ckm * 8 * g.CS * sizeof(float) > 64 * 1024) --ckm;
   g.ckm = ckm;
   g.lds_bytes = (size_t)2 * ckm * 8 * g.CS * sizeof(float);
   return g;
@@ -378,7 +381,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
 
   // pick the tile configuration: time ~ ceil(workgroups / 256 CUs) x (MFMAs per MFMA wave) / efficiency, with the
   // per-configuration efficiency measured on MI355X (tools/tune_conv.py; profiles/r01_tune_conv.txt)
-  static const double kEff[] = {0.80, 0.42, 0.76, 0.52, 1.00, 0.62, 0.84, 0.90, 0.86, 0.74};
+  static const double kEff[] = {0.75, 1.00, 0.80, 0.60, 1.00, 0.65, 0.80, 0.80, 0.75, 0.70};
   int best = -1;
   double best_cost = 1e300;
   Geometry bg{};
@@ -387,8 +390,9 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     if (g_force_cfg >= 0 && i != g_force_cfg) continue;
     const KernelCfg& c = kCfgs[i];
     const int bpx = c.wpx * c.tpx * 32, bco_t = c.wco * c.tco;
-    Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps);
+    Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps, c.tco * c.tpx);
     if (g.lds_bytes > 160 * 1024) continue;
+    if ((1 << g.lgTI) * g.PH * g.PW > ICM_MAXJ * 64) continue;   // PlaneMap capacity
     const long long blocks = (long long)cdiv(ncot, bco_t) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
     const double per_cu = (double)((blocks + 255) / 256);
     const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4;   // per MFMA wave

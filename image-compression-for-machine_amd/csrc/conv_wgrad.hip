@@ -95,7 +95,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
             bsum[k] += v;
           }
         }
-        stage_patch_u<16>(d.gb, pg, b0, TB * 32, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, gbP, ltid, 256);
+        PlaneMap pm;
+        plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+        stage_planes(d.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
       }
       __syncthreads();
     }
@@ -247,6 +249,7 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p) {
     else if (lds_of(2, 1) <= 150 * 1024) {
       p.ta = 2; p.tb = 1; p.np = 4; p.tpg = ntaps <= 16 ? ntaps : (ntaps + 1) / 2; ok = true;
     }
+    if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
     if (ok) p.lds = lds_of(p.ta, p.tb);
   }
   if (!ok) return ICM_ERR_UNSUPPORTED;

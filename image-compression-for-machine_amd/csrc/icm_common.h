@@ -55,45 +55,74 @@ struct PatchGeom {
   int H, W, N, C, act;
   long long bs;
 };
-template <int U>
-__device__ __forceinline__ void stage_patch_u(const float* __restrict__ src, const PatchGeom& g, int c0, int nch,
-                                              int n0, int iyb, int ixb, float* __restrict__ dst, int ltid,
-                                              int nthreads) {
-  // U independent global loads are issued per thread before any LDS store, so a loader wave keeps U*64 requests
-  // in flight: the staging is latency-bound (L2 / HBM round trips), not bandwidth-bound.
-  const int total = nch * g.TIPH * g.PW;
-  const int HW = g.H * g.W;
-  for (int base = 0; base < total; base += nthreads * U) {
-    float v[U];
-    int la[U];
+// Plane-sweep staging: a loader wave owns whole channels; its 64 lanes sweep the (TI x PH x PW) plane of the
+// patch linearly.  The per-lane plane offsets (global and LDS) depend only on the tile, so they are computed
+// once (PlaneMap) and every channel afterwards costs one address add, one load and one LDS store per element,
+// with up to MAXJ loads in flight per lane.
+#define ICM_MAXJ 12
+struct PlaneMap {
+  int goff[ICM_MAXJ];   // offset inside the channel plane (incl. image offset n*bs), -1 = zero fill
+  int loff[ICM_MAXJ];   // offset inside the LDS channel slab, -1 = beyond the plane
+};
+__device__ __forceinline__ void plane_map_init(PlaneMap& m, const PatchGeom& g, int n0, int iyb, int ixb, int lane) {
+  const int plane = g.TIPH * g.PW;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = base + u * nthreads + ltid;
-      v[u] = 0.0f;
-      la[u] = -1;
-      if (e < total) {
-        const uint32_t r = fdiv((uint32_t)e, g.dPW);
-        const int px = e - (int)r * g.PW;
-        const uint32_t c8 = fdiv(r, g.dTIPH);
-        const uint32_t rem = r - c8 * (uint32_t)g.TIPH;
-        const uint32_t ti = fdiv(rem, g.dPH);
-        const int py = (int)(rem - ti * (uint32_t)g.PH);
-        const int c = c0 + (int)c8, n = n0 + (int)ti, iy = iyb + py, ix = ixb + px;
-        if (c < g.C && n < g.N && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-          v[u] = src[(long long)n * g.bs + (long long)c * HW + iy * g.W + ix];
-        const int col = (g.S == 2) ? ((px & 1) * g.PWh + (px >> 1)) : px;
-        la[u] = (int)c8 * g.CS + (int)ti * g.PP + py * g.PWrow + col;
-      }
+  for (int j = 0; j < ICM_MAXJ; ++j) {
+    const int e = lane + 64 * j;
+    m.goff[j] = -1;
+    m.loff[j] = -1;
+    if (e < plane) {
+      const uint32_t r = fdiv((uint32_t)e, g.dPW);
+      const int px = e - (int)r * g.PW;
+      const uint32_t ti = fdiv(r, g.dPH);
+      const int py = (int)(r - ti * (uint32_t)g.PH);
+      const int n = n0 + (int)ti, iy = iyb + py, ix = ixb + px;
+      if (n < g.N && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+        m.goff[j] = ((int)((long long)n * g.bs) + iy * g.W + ix) * 4;   // byte offset (host checks N*bs*4 < 2^31)
+      const int col = (g.S == 2) ? ((px & 1) * g.PWh + (px >> 1)) : px;
+      m.loff[j] = ((int)ti * g.PP + py * g.PWrow + col) * 4;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (la[u] >= 0) dst[la[u]] = apply_act(v[u], g.act);
   }
 }
-__device__ __forceinline__ void stage_patch(const float* __restrict__ src, const PatchGeom& g, int c0, int nch,
-                                            int n0, int iyb, int ixb, float* __restrict__ dst, int ltid,
-                                            int nthreads) {
-  stage_patch_u<8>(src, g, c0, nch, n0, iyb, ixb, dst, ltid, nthreads);
+// stage local channels cl = lw, lw+4, ... < nch (global channel c0 + cl) of the patch into dst.
+// NJR = plane slots per lane rounded up to a divisor of 12; 12/NJR channels are in flight together so that a
+// lane always has 12 independent loads outstanding, whatever the plane size.
+template <int NJR>
+__device__ __forceinline__ void stage_planes_t(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
+                                               int c0, int nch, float* __restrict__ dst, int lw) {
+  // lw must be wave-uniform (readfirstlane): channel bases then live in SGPRs and every load is
+  // global_load_dword v, v_off32, s[base] -- no 64-bit vector address arithmetic in the loader
+  constexpr int CPB = ICM_MAXJ / NJR;
+  const long long HWb = (long long)g.H * g.W * 4;
+  const int nk = (nch - lw + 3) >> 2;   // channels of this loader wave
+  const char* srcb = reinterpret_cast<const char*>(src);
+  char* dstb = reinterpret_cast<char*>(dst);
+  for (int kb = 0; kb < nk; kb += CPB) {
+    float v[ICM_MAXJ];
+#pragma unroll
+    for (int u = 0; u < ICM_MAXJ; ++u) {
+      const int k = kb + u / NJR, j = u % NJR;
+      const int c = c0 + lw + 4 * k;
+      const char* base = srcb + (long long)c * HWb;
+      v[u] = (k < nk && c < g.C && m.goff[j] >= 0) ? *reinterpret_cast<const float*>(base + m.goff[j]) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < ICM_MAXJ; ++u) {
+      const int k = kb + u / NJR, j = u % NJR;
+      if (k < nk && m.loff[j] >= 0)
+        *reinterpret_cast<float*>(dstb + (lw + 4 * k) * g.CS * 4 + m.loff[j]) = apply_act(v[u], g.act);
+    }
+  }
+}
+__device__ __forceinline__ void stage_planes(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
+                                             int c0, int nch, float* __restrict__ dst, int lw) {
+  const int nj = (g.TIPH * g.PW + 63) >> 6;
+  if (nj <= 1) stage_planes_t<1>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 2) stage_planes_t<2>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 3) stage_planes_t<3>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 4) stage_planes_t<4>(src, m, g, c0, nch, dst, lw);
+  else if (nj <= 6) stage_planes_t<6>(src, m, g, c0, nch, dst, lw);
+  else stage_planes_t<12>(src, m, g, c0, nch, dst, lw);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
