@@ -1,0 +1,71 @@
+"""CPU, world_size=2 over gloo: the data-parallel plumbing of icm_amd.trainer (bucket layout of the flat
+gradient buffer, bucketed all-reduce, mean-of-shards semantics).  Kernels are not involved here."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "image-compression-for-machine_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from icm_amd.trainer import BUCKETS, FlatParams, GradReducer
+        from icm_amd.zoo import models
+        torch.manual_seed(0)
+        net = models["cnn"]()
+        flat = FlatParams(net, torch.device("cpu"))
+        # every main parameter lives in exactly one bucket range; ranges tile the flat buffer
+        assert flat.bucket_ranges[0][0] == 0 and flat.bucket_ranges[-1][1] == flat.n_main
+        for (a0, b0), (a1, b1) in zip(flat.bucket_ranges, flat.bucket_ranges[1:]):
+            assert b0 == a1
+        assert sum(p.numel() for _, p in flat.main) == 75235779 - 192 * 3
+        names0 = {n.split(".")[0] for n, _ in flat.main}
+        assert names0 == {p for b in BUCKETS for p in b}
+        # parameters are views of the flat buffer
+        flat.p.fill_(1.5)
+        assert all(float(p.data.flatten()[0]) == 1.5 for _, p in flat.main)
+        red = GradReducer(flat.g, flat.bucket_ranges)
+        assert red.world == world
+        flat.g.copy_(torch.arange(flat.n_main, dtype=torch.float32) % 97 * (rank + 1))
+        expect = torch.arange(flat.n_main, dtype=torch.float32) % 97 * sum(r + 1 for r in range(world))
+        for b in range(len(flat.bucket_ranges)):   # launched bucket by bucket as backward would
+            red.launch(b)
+        red.finish()
+        assert torch.equal(flat.g, expect)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_buckets_and_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
