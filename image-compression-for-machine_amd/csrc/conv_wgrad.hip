@@ -19,11 +19,15 @@ namespace icm {
 
 #define WG_MAX_TAPS 32
 
-struct WgDesc {
+#define WG_MAXG 32
+struct WgPtrs {
   const float* gs;
   const float* gb;
   float* ws;
   float* dbias_ws;   // [nsplit][Ca] or null
+};
+struct WgDesc {
+  WgPtrs g[WG_MAXG];   // problems of identical geometry: blockIdx.y selects one (deferred, batched wgrads)
   long long gs_bs;
   PatchGeom pg;      // big-grid tensor + patch layout (identity colmap)
   int Ca, OH, OW, act_s;
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   int* poff = reinterpret_cast<int*>(smem + 2 * bufsz);  // [npx]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool loader = wave >= 4;
+  const WgPtrs G = d.g[blockIdx.y];
 
   int bid = blockIdx.x;
   const int at = bid % d.natile; bid /= d.natile;
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
 
   if (loader) {
     const int ltid = tid - 256;
-    const bool do_bias = d.dbias_ws != nullptr && bt == 0 && tg == 0;
+    const bool do_bias = G.dbias_ws != nullptr && bt == 0 && tg == 0;
     float bsum[TA * 8];
 #pragma unroll
     for (int k = 0; k < TA * 8; ++k) bsum[k] = 0.0f;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
         float* gbP = gsT + gs_sz;
         const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
         const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
-        const float* src = d.gs + (long long)n * d.gs_bs + oy * d.OW + ox;
+        const float* src = G.gs + (long long)n * d.gs_bs + oy * d.OW + ox;
 #pragma unroll
         for (int k = 0; k < TA * 8; ++k) {
           const int a = a_sub + a_step * k, ca = a0 + a;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
         }
         PlaneMap pm;
         plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-        stage_planes(d.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        stage_planes(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
       }
       __syncthreads();
     }
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
         for (int o = 32; o > 0; o >>= 1)
           if (o < npx) s += __shfl_xor(s, o, 64);   // lanes sharing a channel are npx consecutive lanes
         const int a = a_sub + a_step * k, ca = a0 + a;
-        if (p == 0 && a < TA * 32 && ca < d.Ca) d.dbias_ws[(long long)split * d.Ca + ca] = s;
+        if (p == 0 && a < TA * 32 && ca < d.Ca) G.dbias_ws[(long long)split * d.Ca + ca] = s;
       }
     }
     return;
@@ -170,50 +175,70 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
       for (int r = 0; r < 16; ++r) {
         const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (a < d.Ca && b < pg.C)
-          d.ws[(((long long)split * d.ntaps + tap) * d.Ca + a) * pg.C + b] = acc[m * TA + ta][r];
+          G.ws[(((long long)split * d.ntaps + tap) * d.Ca + a) * pg.C + b] = acc[m * TA + ta][r];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// dw[(a*Cb + b)*ntaps + t] (+)= sum_s ws[((s*ntaps + t)*Ca + a)*Cb + b]
-// workgroup = one a, 32 consecutive b: reads 128-B rows per tap, transposes through LDS, writes ntaps*32
-// contiguous floats of the canonical layout.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                           int Ca, int Cb, int ntaps, int nsplit, int accum) {
+// dw[(a*Cb + b)*ntaps + t] (+)= sum_s ws[((s*ntaps + t)*Ca + a)*Cb + b]      (+ db[a] (+)= sum_s dbias_ws[s][a])
+// workgroup = one a, 32 consecutive b: reads 128-B rows per tap (4 splits in flight), transposes through LDS,
+// writes ntaps*32 contiguous floats of the canonical layout.  blockIdx.y = problem of the group; the last
+// blockIdx.x rows of the grid reduce the fused bias gradients.
+struct RedPtrs {
+  const float* ws;
+  float* dw;
+  const float* dbias_ws;
+  float* dbias;
+  int accum, accum_bias;
+};
+struct RedDesc {
+  RedPtrs g[WG_MAXG];
+  int Ca, Cb, ntaps, nsplit, nwblocks;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   __shared__ float tile[WG_MAX_TAPS][33];
+  const RedPtrs G = d.g[blockIdx.y];
+  const int Ca = d.Ca, Cb = d.Cb, ntaps = d.ntaps, nsplit = d.nsplit;
+  if ((int)blockIdx.x >= d.nwblocks) {   // bias part
+    if (!G.dbias) return;
+    const int a = ((int)blockIdx.x - d.nwblocks) * 256 + threadIdx.x;
+    if (a >= Ca) return;
+    float s = 0.0f;
+    for (int k = 0; k < nsplit; ++k) s += G.dbias_ws[(long long)k * Ca + a];
+    if (G.accum_bias) s += G.dbias[a];
+    G.dbias[a] = s;
+    return;
+  }
   const int nbt = (Cb + 31) / 32;
   const int a = blockIdx.x / nbt, b0 = (blockIdx.x % nbt) * 32;
   const long long slab = (long long)Ca * Cb * ntaps;
   for (int e = threadIdx.x; e < ntaps * 32; e += 256) {
     const int t = e >> 5, bl = e & 31;
-    float s = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (b0 + bl < Cb) {
-      const long long idx = ((long long)t * Ca + a) * Cb + b0 + bl;
-      for (int k = 0; k < nsplit; ++k) s += ws[k * slab + idx];
+      const float* p = G.ws + ((long long)t * Ca + a) * Cb + b0 + bl;
+      int k = 0;
+      for (; k + 4 <= nsplit; k += 4) {
+        s0 += p[(k + 0) * slab];
+        s1 += p[(k + 1) * slab];
+        s2 += p[(k + 2) * slab];
+        s3 += p[(k + 3) * slab];
+      }
+      for (; k < nsplit; ++k) s0 += p[k * slab];
     }
-    tile[t][bl] = s;
+    tile[t][bl] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   const int nb = min(32, Cb - b0);
-  float* o = dw + ((long long)a * Cb + b0) * ntaps;
+  float* o = G.dw + ((long long)a * Cb + b0) * ntaps;
   for (int e = threadIdx.x; e < nb * ntaps; e += 256) {
     const int bl = e / ntaps, t = e - bl * ntaps;
     float v = tile[t][bl];
-    if (accum) v += o[e];
+    if (G.accum) v += o[e];
     o[e] = v;
   }
-}
-
-__global__ void bias_reduce_kernel(const float* __restrict__ ws, float* __restrict__ db, int Ca, int nsplit,
-                                   int accum) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= Ca) return;
-  float s = 0.0f;
-  for (int k = 0; k < nsplit; ++k) s += ws[(long long)k * Ca + a];
-  if (accum) s += db[a];
-  db[a] = s;
 }
 
 struct WgPlan {
@@ -273,18 +298,34 @@ int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a) {
   return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
 }
 
-int icm_conv_wgrad(const icm_wgrad_args* a, void* stream_) {
+static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   using namespace icm;
-  if (!a || !a->dw || !a->ws) return ICM_ERR_ARG;
+  if (!arr || n < 1 || n > WG_MAXG) return ICM_ERR_ARG;
+  const icm_wgrad_args* a = &arr[0];
   WgPlan p;
   int rc = plan_wgrad(*a, p);
   if (rc) return rc;
-  hipStream_t stream = (hipStream_t)stream_;
+  for (int i = 0; i < n; ++i) {
+    const icm_wgrad_args& b = arr[i];
+    if (!b.gs || !b.gb || !b.dw || !b.ws) return ICM_ERR_ARG;
+    if (b.Ca != a->Ca || b.Cb != a->Cb || b.OH != a->OH || b.OW != a->OW || b.H != a->H || b.W != a->W ||
+        b.N != a->N || b.KH != a->KH || b.KW != a->KW || b.stride != a->stride || b.pad != a->pad ||
+        b.act_s != a->act_s || b.act_b != a->act_b || b.gs_bs != a->gs_bs || b.gb_bs != a->gb_bs)
+      return ICM_ERR_ARG;
+  }
+  if ((long long)a->N * a->gb_bs * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   const int ntaps = a->KH * a->KW;
-  WgDesc d;
-  d.gs = a->gs; d.gb = a->gb; d.ws = a->ws; d.gs_bs = a->gs_bs;
   const long long slab_all = (long long)p.nsplit * ntaps * a->Ca * a->Cb;
-  d.dbias_ws = a->dbias ? a->ws + slab_all : nullptr;
+  WgDesc d;
+  RedDesc r;
+  for (int i = 0; i < WG_MAXG; ++i) {
+    const icm_wgrad_args& b = arr[i < n ? i : 0];
+    d.g[i].gs = b.gs; d.g[i].gb = b.gb; d.g[i].ws = b.ws;
+    d.g[i].dbias_ws = b.dbias ? b.ws + slab_all : nullptr;
+    r.g[i].ws = b.ws; r.g[i].dw = b.dw; r.g[i].dbias_ws = d.g[i].dbias_ws; r.g[i].dbias = b.dbias;
+    r.g[i].accum = b.accum; r.g[i].accum_bias = b.accum_bias;
+  }
+  d.gs_bs = a->gs_bs;
   PatchGeom& pg = d.pg;
   pg.PW = p.PW; pg.PH = p.PH; pg.PWrow = p.PW; pg.PWh = 0; pg.PP = p.PP; pg.CS = p.CS; pg.S = 1;
   pg.TIPH = (1 << p.lgTI) * p.PH;
@@ -307,18 +348,23 @@ int icm_conv_wgrad(const icm_wgrad_args* a, void* stream_) {
   else fn = wgrad_kernel<2, 1, 4>;
   if (p.lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
-  hipLaunchKernelGGL(fn, dim3((unsigned)nblk), dim3(512), p.lds, stream, d);
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk, n), dim3(512), p.lds, stream, d);
   ICM_CHECK_LAUNCH();
-  const int rblocks = a->Ca * cdiv(a->Cb, 32);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, a->ws, a->dw, a->Ca, a->Cb, ntaps,
-                     p.nsplit, a->accum);
+  r.Ca = a->Ca; r.Cb = a->Cb; r.ntaps = ntaps; r.nsplit = p.nsplit;
+  r.nwblocks = a->Ca * cdiv(a->Cb, 32);
+  bool any_bias = false;
+  for (int i = 0; i < n; ++i) any_bias |= arr[i].dbias != nullptr;
+  const int rblocks = r.nwblocks + (any_bias ? cdiv(a->Ca, 256) : 0);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks, n), dim3(256), 0, stream, r);
   ICM_CHECK_LAUNCH();
-  if (a->dbias) {
-    hipLaunchKernelGGL(bias_reduce_kernel, dim3(cdiv(a->Ca, 256)), dim3(256), 0, stream, d.dbias_ws, a->dbias, a->Ca,
-                       p.nsplit, a->accum_bias);
-    ICM_CHECK_LAUNCH();
-  }
   return ICM_OK;
+}
+
+int icm_conv_wgrad(const icm_wgrad_args* a, void* stream_) {
+  return wgrad_grouped(a, 1, (hipStream_t)stream_);
+}
+int icm_conv_wgrad_grouped(const icm_wgrad_args* arr, int n, void* stream_) {
+  return wgrad_grouped(arr, n, (hipStream_t)stream_);
 }
 
 }  // extern "C"

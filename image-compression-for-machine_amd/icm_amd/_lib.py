@@ -60,7 +60,7 @@ _lib = None
 SYMBOLS = [
     "icm_strerror", "icm_version", "icm_conv_run", "icm_conv_run_grouped", "icm_conv2d_fwd", "icm_conv2d_dgrad",
     "icm_convT2d_fwd", "icm_convT2d_dgrad", "icm_packed_weight_floats", "icm_pack_weights",
-    "icm_wgrad_workspace_floats", "icm_conv_wgrad", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
+    "icm_wgrad_workspace_floats", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
@@ -87,6 +87,7 @@ def lib():
             getattr(L, n).argtypes = [C.POINTER(ConvArgs), vp]
         L.icm_wgrad_workspace_floats.argtypes = [C.POINTER(WgradArgs)]
         L.icm_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
+        L.icm_conv_wgrad_grouped.argtypes = [C.POINTER(WgradArgs), i32, vp]
         L.icm_channel_sum.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp]
         L.icm_nonneg_fwd.argtypes = [vp, vp, i64, f32, f32, vp]
         L.icm_nonneg_bwd.argtypes = [vp, vp, vp, i64, f32, i32, vp]

@@ -57,6 +57,7 @@ class Tape:
         self.stopped = set()
         self._packed: Dict[tuple, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
+        self.wjobs: list = []
         self.st = L.stream()
 
     # ---- gradient bookkeeping
@@ -92,6 +93,7 @@ class Tape:
         for f in reversed(self.bw):
             f()
         self.bw = []
+        flush_wgrads(self)
 
     # ---- helpers
     def workspace(self, nfloats: int, device) -> torch.Tensor:
@@ -146,6 +148,45 @@ def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NON
     ws = tape.workspace(n, gs.device)
     a.ws = ptr(ws)
     check(L.lib().icm_conv_wgrad(C.byref(a), tape.st), "conv_wgrad")
+
+
+def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
+                dbias=None, accum_bias=0):
+    """Queue a weight-gradient problem.  Nothing but the optimiser consumes a weight gradient, so problems are
+    collected while the tape unwinds and issued in batches of identical geometry (flush_wgrads)."""
+    N, _, OH, OW = gs.shape
+    _, _, H, W = gb.shape
+    key = (Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, bs(gs), bs(gb), dbias is not None)
+    tape.wjobs.append((key, gs, gb, dw, accum, dbias, accum_bias))
+
+
+def flush_wgrads(tape):
+    if not tape.wjobs:
+        return
+    groups: Dict[tuple, list] = {}
+    for job in tape.wjobs:
+        groups.setdefault(job[0], []).append(job)
+    tape.wjobs = []
+    lib = L.lib()
+    for key, jobs in groups.items():
+        Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, gsb, gbb, _ = key
+        for i0 in range(0, len(jobs), 32):
+            chunk = jobs[i0:i0 + 32]
+            arr = (L.WgradArgs * len(chunk))()
+            for a, (_, gs, gb, dw, accum, dbias, accum_bias) in zip(arr, chunk):
+                a.gs, a.gs_bs, a.Ca, a.OH, a.OW, a.act_s = ptr(gs), gsb, Ca, OH, OW, act_s
+                a.gb, a.gb_bs, a.Cb, a.H, a.W, a.act_b = ptr(gb), gbb, Cb, H, W, act_b
+                a.N, a.KH, a.KW, a.stride, a.pad = N, KH, KW, stride, pad
+                a.dw, a.accum = ptr(dw), accum
+                a.dbias, a.accum_bias = ptr(dbias), accum_bias
+            n = lib.icm_wgrad_workspace_floats(C.byref(arr[0]))
+            if n < 0:
+                raise ValueError("icm wgrad: invalid geometry")
+            n = (n + 63) // 64 * 64
+            ws = tape.workspace(n * len(chunk), chunk[0][1].device)
+            for j, a in enumerate(arr):
+                a.ws = ptr(ws) + 4 * n * j
+            check(lib.icm_conv_wgrad_grouped(arr, len(chunk), tape.st), "conv_wgrad_grouped")
 
 
 def accumulate(tape, dst_t, src, mul_dgelu_of=None):
@@ -233,11 +274,11 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             gw, acc = tape.grad_for_write(w)
             if not transposed:
                 gb_, accb = tape.grad_for_write(b) if fuse_b else (None, 0)
-                wgrad_launch(tape, dy, x, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=act,
-                             accum=acc, dbias=gb_, accum_bias=accb)
+                wgrad_defer(tape, dy, x, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=act,
+                            accum=acc, dbias=gb_, accum_bias=accb)
             else:
-                wgrad_launch(tape, x, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=act,
-                             accum=acc)
+                wgrad_defer(tape, x, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=act,
+                            accum=acc)
         if tape.wants(x):
             gx, acc = tape.grad_for_write(x)
             if act == ACT_GELU:
@@ -257,6 +298,67 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
 
     tape.bw.append(bwd)
     return y
+
+
+def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,
+                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, accum=0):
+    n = len(xs)
+    arr = (L.ConvArgs * n)()
+    for i, a in enumerate(arr):
+        x, y = xs[i], ys[i]
+        N, _, H, W = x.shape
+        a.x, a.x_bs, a.N, a.Cin, a.H, a.W = ptr(x), bs(x), N, Cin, H, W
+        a.wp, a.bias = ptr(wps[i]), ptr(biases[i]) if biases is not None else 0
+        a.y, a.y_bs, a.Cout, a.OH, a.OW = ptr(y), bs(y), Cout, OH, OW
+        a.KH, a.KW, a.stride, a.pad = KH, KW, stride, pad
+        a.transposed, a.pro_act, a.epi = int(transposed), pro_act, epi
+        aux = auxs[i] if auxs is not None else None
+        a.aux, a.aux_bs = ptr(aux), bs(aux)
+        a.accum = accum
+        if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)):
+            raise ValueError("grouped conv: members must share strides")
+    check(L.lib().icm_conv_run_grouped(arr, n, tape.st), "conv_run_grouped")
+
+
+def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1):
+    """The same stride-1 convolution shape applied to several independent (input, weight) pairs in ONE launch
+    (cc_mean_transforms[i] || cc_scale_transforms[i], cnn.py:164-168).  Returns the list of pre-activation outputs."""
+    n = len(xvs)
+    x0, act = xvs[0].t, xvs[0].act
+    N, Cin, H, W = x0.shape
+    Cout, ci, KH, KW = ws[0].shape
+    assert all(v.act == act and v.t.shape == x0.shape for v in xvs) and all(w.shape == ws[0].shape for w in ws)
+    if ci != Cin:
+        raise ValueError("conv2d_group: channel mismatch")
+    OH, OW = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
+    wps = [tape.pack(w, Cout, Cin, KH, KW, 1, 0, 1, pad) for w in ws]
+    ys = [new((N, Cout, OH, OW), x0.device) for _ in range(n)]
+    conv_launch_grouped(tape, [v.t for v in xvs], wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
+                        transposed=0, OH=OH, OW=OW, pro_act=act)
+    if not tape.need_grad:
+        return ys
+
+    def bwd():
+        dys = [tape.grad_of(y) for y in ys]
+        if any(d is None for d in dys):
+            raise RuntimeError("conv2d_group: every member needs a gradient")
+        gxs, accs = [], []
+        for v, w, b, dy in zip(xvs, ws, bs_, dys):
+            gw, acc = tape.grad_for_write(w)
+            gb_, accb = tape.grad_for_write(b)
+            wgrad_defer(tape, dy, v.t, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=1, pad=pad, act_b=act, accum=acc,
+                        dbias=gb_, accum_bias=accb)
+            gx, ax = tape.grad_for_write(v.t)
+            gxs.append(gx)
+            accs.append(ax)
+        assert len(set(accs)) == 1
+        wpb = [tape.pack(w, Cin, Cout, KH, KW, 0, 1, 1, pad) for w in ws]
+        conv_launch_grouped(tape, dys, wpb, None, gxs, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=1, pad=pad,
+                            transposed=1, OH=H, OW=W, epi=EPI_MUL_DGELU if act == ACT_GELU else EPI_NONE,
+                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, accum=accs[0])
+
+    tape.bw.append(bwd)
+    return ys
 
 
 def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> torch.Tensor:

@@ -68,6 +68,16 @@ def _chain(tape, P, p, xv: VT, strides=(1, 1, 1, 1, 1), out=None, lrp_aux=None):
     return t
 
 
+def _chain_pair(tape, P, p1, p2, xv1: VT, xv2: VT):
+    """cc_mean_transforms[i] and cc_scale_transforms[i] are independent and shape-identical: run each of
+    their five convolutions as one grouped launch (forward and dgrad)."""
+    for i in (0, 2, 4, 6, 8):
+        t1, t2 = E.conv2d_group(tape, [xv1, xv2], [P[f"{p1}.{i}.weight"], P[f"{p2}.{i}.weight"]],
+                                [P[f"{p1}.{i}.bias"], P[f"{p2}.{i}.bias"]], pad=1)
+        xv1, xv2 = VT(t1, ACT_GELU), VT(t2, ACT_GELU)
+    return t1, t2
+
+
 def _h_s(tape, P, p, z_hat, out):
     """h_mean_s / h_scale_s (cnn.py:66-88): PixelShuffle fused into the subpel convs' stores."""
     u = E.conv2d(tape, VT(z_hat), P[p + ".0.weight"], P[p + ".0.bias"], pad=1)
@@ -152,8 +162,7 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
         k = min(i, max_support)
         ch = slice(i * sc_, (i + 1) * sc_)
         ms, ss = MS[:, :M + sc_ * k], SS[:, :M + sc_ * k]
-        mu = _chain(tape, P, f"cc_mean_transforms.{i}", VT(ms))
-        sc = _chain(tape, P, f"cc_scale_transforms.{i}", VT(ss))
+        mu, sc = _chain_pair(tape, P, f"cc_mean_transforms.{i}", f"cc_scale_transforms.{i}", VT(ms), VT(ss))
         LS = E.new((N, M + sc_ * (k + 1), h, w), dev)
         yh_pre = LS[:, M + sc_ * k:]
         if need:

@@ -175,7 +175,7 @@ class Trainer:
         tape.bind_grad(z_lik, dlz, True)
         # ---- backward with bucketed all-reduce overlapped (markers fire as the tape unwinds)
         for name, idx in sorted(marks.items(), key=lambda kv: -kv[1]):
-            tape.bw.insert(idx, (lambda b=name: self.reducer.launch(b)))
+            tape.bw.insert(idx, (lambda b=name: (E.flush_wgrads(tape), self.reducer.launch(b))))
         tape.backward()
         self.reducer.launch(len(BUCKETS) - 1)   # g_a: last gradients to complete
         if len(f.bucket_ranges) > len(BUCKETS):

@@ -103,6 +103,10 @@ typedef struct icm_wgrad_args {
 } icm_wgrad_args;
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a);
 int icm_conv_wgrad(const icm_wgrad_args* a, void* stream);
+/* up to 32 weight-gradient problems of identical geometry in one launch pair (deferred, batched wgrads: a
+ * weight gradient has no consumer but the optimiser, so the 150 small slice-chain wgrads are collected during
+ * backward and issued together); every arr[i].ws is that problem's own workspace */
+int icm_conv_wgrad_grouped(const icm_wgrad_args* arr, int n, void* stream);
 
 /* out[c] (+)= sum_{n,p} x[n,c,p]   (bias gradients; GDN d_beta) */
 int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, void* stream);
