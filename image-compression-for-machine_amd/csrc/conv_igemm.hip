@@ -168,36 +168,66 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
 #pragma unroll
   for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[wl[a]];
 
-  int toff_nxt = d.tapoff[0];
+  const int toff_lane = d.tapoff[lane & 31];   // tap offsets live in one VGPR; v_readlane picks entry t
   __syncthreads();  // patch of chunk 0 staged
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const float* cur = smem + (chunk & 1) * bufsz;
     const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
-    for (int sub = 0; sub < nsub; ++sub) {
-      const float* cb8 = cur + sub * 8 * pg.CS;
-      for (int t = 0; t < d.ntaps; ++t) {
-        f32x4 a_cur[TCO];
+    const int nq = nsub * d.ntaps;
+    // software pipeline over (8-channel group, tap) steps, branch-free so that each step is one basic block:
+    // B fragments of step q+1 are read from LDS and A fragments (weights) of step Q+1 from L2 while the MFMAs of
+    // step q issue; the last step of a chunk re-reads its own fragments
+    float bv_n[4][TPX];
+    {
+      const float* bp = cur + __builtin_amdgcn_readlane(toff_lane, 0);
 #pragma unroll
-        for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
-        ++Q;
-        if (Q < Qtot) {
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(long long)Q * qstride + wl[a]];
+        for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
+    }
+    int sub = 0, t = 0;
+    for (int q = 0; q < nq; ++q) {
+      f32x4 a_cur[TCO];
+      float bv[4][TPX];
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tp = 0; tp < TPX; ++tp) bv[j][tp] = bv_n[j][tp];
+      Q = min(Q + 1, Qtot - 1);
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(long long)Q * qstride + wl[a]];
+      {
+        const bool last = q + 1 == nq;
+        int tn = t + 1, subn = sub;
+        const bool wrap = tn == d.ntaps;
+        tn = wrap ? 0 : tn;
+        subn = wrap ? sub + 1 : sub;
+        t = last ? t : tn;
+        sub = last ? sub : subn;
+        const float* bp = cur + sub * 8 * pg.CS + __builtin_amdgcn_readlane(toff_lane, t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TCO; ++a)
+#pragma unroll
+          for (int tp = 0; tp < TPX; ++tp)
+            acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[j][tp], acc[a][tp], 0, 0, 0);
+      // issue order: after each MFMA (64 cycles of matrix pipe) slot in one fragment fetch of the NEXT step
+#pragma unroll
+      for (int m = 0; m < 4 * TCO * TPX; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < TCO) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (m < 4 * TPX) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        const float* bp = cb8 + toff_nxt;
-        toff_nxt = d.tapoff[t + 1 < d.ntaps ? t + 1 : 0];
-        float bv[4][TPX];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int tp = 0; tp < TPX; ++tp) bv[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int a = 0; a < TCO; ++a)
-#pragma unroll
-            for (int tp = 0; tp < TPX; ++tp)
-              acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[j][tp], acc[a][tp], 0, 0, 0);
       }
     }
     __syncthreads();

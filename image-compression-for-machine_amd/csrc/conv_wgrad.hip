@@ -35,18 +35,18 @@ struct WgDesc {
   int lgTW, lgTH, lgTI, lgNPX;
   int tiles_x, tiles_y, tiles_n, ntiles, nsplit;
   int natile, nbtile, ngroups;
+  int po_h;                    // patch offset of pixel 2kp+1 relative to pixel 2kp
   int tapoff[WG_MAX_TAPS];
+  int pe[32];                  // patch offset of pixel 2kp (wave-uniform: scalar loads)
 };
 
-template <int TA, int TB, int NP>
+template <int TA, int TB, int NACC>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NACC = TA * NP;
   const PatchGeom& pg = d.pg;
   const int npx = 1 << d.lgNPX, grow = npx + 1;   // pixels per tile (16/32/64), gs row stride
   const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
   const int bufsz = gs_sz + gb_sz;
-  int* poff = reinterpret_cast<int*>(smem + 2 * bufsz);  // [npx]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool loader = wave >= 4;
   const WgPtrs G = d.g[blockIdx.y];
@@ -60,11 +60,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   const int nt = min(d.tpg, d.ntaps - t0);
   const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
   const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
-
-  if (tid < npx) {
-    const int tx = tid & TWm, ty = (tid >> d.lgTW) & THm, ti = tid >> (d.lgTW + d.lgTH);
-    poff[tid] = ti * pg.PP + ty * d.S * pg.PW + tx * d.S;
-  }
 
   if (loader) {
     const int ltid = tid - 256;
@@ -121,16 +116,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
 
   // ------------------------------------------------------------------ MFMA waves
   const int h = lane >> 5, l31 = lane & 31;
-  // pair m of this wave: q = wave + 4*m -> (tap = q / TB, tb = q % TB); invalid pairs repeat pair 0 and are not stored
-  int boffs[NP];
-  bool pvalid[NP];
+  // accumulator i of this wave: tile q = wave + 4*i -> (tap, ta, tb); all wave-uniform
+  const int ntile = nt * TA * TB;
+  int boffs[NACC];
+  int tsel[NACC];
 #pragma unroll
-  for (int m = 0; m < NP; ++m) {
-    const int q = wave + 4 * m;
-    pvalid[m] = q < nt * TB;
-    const int qq = pvalid[m] ? q : 0;
-    const int tap = qq / TB, tb = qq % TB;
-    boffs[m] = (tb * 32 + l31) * pg.CS + d.tapoff[t0 + tap];
+  for (int i = 0; i < NACC; ++i) {
+    const int q = wave + 4 * i;
+    const int qq = q < ntile ? q : 0;
+    const int tap = qq / (TA * TB), rem = qq % (TA * TB);
+    const int ta = rem / TB, tb = rem % TB;
+    tsel[i] = q < ntile ? ta : -1;
+    boffs[i] = (tb * 32 + l31) * pg.CS + d.tapoff[t0 + tap] + h * d.po_h;
   }
   f32x16 acc[NACC];
 #pragma unroll
@@ -138,45 +135,70 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+  const int pe_lane = d.pe[lane & 31];   // pixel-pair offsets live in one VGPR; v_readlane picks entry kp
   __syncthreads();  // tile 0 staged
+  const int nkp = npx >> 1;
   for (int it = 0; it < niter; ++it) {
     const float* gsT = smem + (it & 1) * bufsz;
     const float* gbP = gsT + gs_sz;
     const float* arow = gsT + l31 * grow + h;
-    const int nkp = npx >> 1;
-#pragma unroll 2
+    // software pipeline over pixel pairs: fragments of kp+1 are in flight while the MFMAs of kp issue
+    float av_n[TA], bv_n[NACC];
+    {
+      const int po = __builtin_amdgcn_readlane(pe_lane, 0);
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta) av_n[ta] = arow[ta * 32 * grow];
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) bv_n[i] = gbP[boffs[i] + po];
+    }
     for (int kp = 0; kp < nkp; ++kp) {
-      const int po = poff[2 * kp + h];
-      float av[TA];
+      float av[TA], bv[NACC];
 #pragma unroll
-      for (int ta = 0; ta < TA; ++ta) av[ta] = arow[ta * 32 * grow + 2 * kp];
+      for (int ta = 0; ta < TA; ++ta) av[ta] = av_n[ta];
 #pragma unroll
-      for (int m = 0; m < NP; ++m) {
-        if (pvalid[m]) {
-          const float bv = gbP[boffs[m] + po];
+      for (int i = 0; i < NACC; ++i) bv[i] = bv_n[i];
+      {  // branch-free prefetch (the last iteration re-reads its own fragments): one basic block, so the
+         // scheduler can slot the LDS reads between MFMAs
+        const int kn = min(kp + 1, nkp - 1);
+        const int po = __builtin_amdgcn_readlane(pe_lane, kn);
 #pragma unroll
-          for (int ta = 0; ta < TA; ++ta)
-            acc[m * TA + ta] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv, acc[m * TA + ta], 0, 0, 0);
-        }
+        for (int ta = 0; ta < TA; ++ta) av_n[ta] = arow[ta * 32 * grow + 2 * kn];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) bv_n[i] = gbP[boffs[i] + po];
+      }
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        // no branch: tiles beyond this wave's share recompute tile 0 into an accumulator that is never stored
+        float a = av[0];
+#pragma unroll
+        for (int ta = 1; ta < TA; ++ta) a = (tsel[i] == ta) ? av[ta] : a;
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[i], acc[i], 0, 0, 0);
+      }
+      // issue order: one MFMA, then (while the matrix pipe is busy for 64 cycles) the VALU address math and one
+      // LDS read of the NEXT pixel pair -- the wave is in-order, so reads placed after the MFMA block would wait
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if (i < TA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
     }
     __syncthreads();
   }
 
 #pragma unroll
-  for (int m = 0; m < NP; ++m) {
-    if (!pvalid[m]) continue;
-    const int q = wave + 4 * m;
-    const int tap = t0 + q / TB, tb = q % TB;
+  for (int i = 0; i < NACC; ++i) {
+    if (tsel[i] < 0) continue;
+    const int q = wave + 4 * i;
+    const int tap = t0 + q / (TA * TB), rem = q % (TA * TB);
+    const int ta = rem / TB, tb = rem % TB;
     const int b = b0 + tb * 32 + l31;
 #pragma unroll
-    for (int ta = 0; ta < TA; ++ta) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (a < d.Ca && b < pg.C)
-          G.ws[(((long long)split * d.ntaps + tap) * d.Ca + a) * pg.C + b] = acc[m * TA + ta][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (a < d.Ca && b < pg.C)
+        G.ws[(((long long)split * d.ntaps + tap) * d.Ca + a) * pg.C + b] = acc[i][r];
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -242,13 +264,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
 }
 
 struct WgPlan {
-  int ta, tb, np, tpg;
+  int ta, tb, nacc, tpg;
   int lgTW, lgTH, lgTI, lgNPX, PH, PW, PP, CS;
   int tiles_x, tiles_y, tiles_n, ntiles, nsplit, natile, nbtile, ngroups;
   size_t lds;
 };
 
-static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p) {
+static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
   if (!a.gs || !a.gb || a.N <= 0 || a.Ca <= 0 || a.Cb <= 0 || a.KH * a.KW > WG_MAX_TAPS) return ICM_ERR_ARG;
   if (a.stride != 1 && a.stride != 2) return ICM_ERR_UNSUPPORTED;
   if (a.OH != (a.H + 2 * a.pad - a.KH) / a.stride + 1 || a.OW != (a.W + 2 * a.pad - a.KW) / a.stride + 1)
@@ -267,12 +289,13 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p) {
     p.CS = TI * p.PP;
     if ((p.CS & 1) == 0) p.CS += 1;
     auto lds_of = [&](int ta, int tb) {
-      return (size_t)2 * (ta * 32 * ((1 << lg) + 1) + tb * 32 * p.CS) * 4 + (size_t)(1 << lg) * 4;
+      return (size_t)2 * (ta * 32 * ((1 << lg) + 1) + tb * 32 * p.CS) * 4;
     };
-    if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) { p.ta = 4; p.tb = 4; p.np = 1; p.tpg = 1; ok = true; }
-    else if (ntaps <= 10 && lds_of(2, 2) <= 150 * 1024) { p.ta = 2; p.tb = 2; p.np = 5; p.tpg = ntaps; ok = true; }
-    else if (lds_of(2, 1) <= 150 * 1024) {
-      p.ta = 2; p.tb = 1; p.np = 4; p.tpg = ntaps <= 16 ? ntaps : (ntaps + 1) / 2; ok = true;
+    if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) { p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; ok = true; }
+    else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) { p.ta = 2; p.tb = 2; p.nacc = 9; p.tpg = ntaps; ok = true; }
+    else if (lds_of(2, 1) <= 150 * 1024) {   // <=14 taps per group x 2 a-tiles = 28 tiles = 7 per MFMA wave
+      p.ta = 2; p.tb = 1; p.nacc = 7; p.tpg = ntaps <= 14 ? ntaps : (ntaps + 1) / 2; ok = true;
+      if (p.tpg > 14) ok = false;
     }
     if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
     if (ok) p.lds = lds_of(p.ta, p.tb);
@@ -282,9 +305,11 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p) {
   p.tiles_x = cdiv(a.OW, TW); p.tiles_y = cdiv(a.OH, TH); p.tiles_n = cdiv(a.N, TI);
   p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
   p.natile = cdiv(a.Ca, 32 * p.ta); p.nbtile = cdiv(a.Cb, 32 * p.tb); p.ngroups = cdiv(ntaps, p.tpg);
-  const int base = p.natile * p.nbtile * p.ngroups;
-  // ~3 workgroups per CU in flight; small problems get one pixel tile per workgroup (latency over reuse)
-  p.nsplit = std::max(1, std::min(p.ntiles, cdiv(768, base)));
+  const int base = p.natile * p.nbtile * p.ngroups * std::max(1, nproblems);
+  // whole rounds of workgroups over the 256 CUs (occ per CU by LDS): no tail round, fewest slabs
+  const int occ = std::max<int>(1, (int)((160 * 1024) / p.lds));
+  const int target = 256 * std::min(occ, 2);
+  p.nsplit = std::max(1, std::min(p.ntiles, target / std::max(1, base)));
   return ICM_OK;
 }
 
@@ -303,7 +328,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   if (!arr || n < 1 || n > WG_MAXG) return ICM_ERR_ARG;
   const icm_wgrad_args* a = &arr[0];
   WgPlan p;
-  int rc = plan_wgrad(*a, p);
+  int rc = plan_wgrad(*a, p, n);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) {
     const icm_wgrad_args& b = arr[i];
@@ -341,11 +366,20 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   for (int t = 0; t < WG_MAX_TAPS; ++t) d.tapoff[t] = 0;
   for (int kh = 0; kh < a->KH; ++kh)
     for (int kw = 0; kw < a->KW; ++kw) d.tapoff[kh * a->KW + kw] = kh * p.PW + kw;
+  {
+    const int TWm = (1 << p.lgTW) - 1, THm = (1 << p.lgTH) - 1;
+    auto off = [&](int px) {
+      const int tx = px & TWm, ty = (px >> p.lgTW) & THm, ti = px >> (p.lgTW + p.lgTH);
+      return ti * p.PP + ty * a->stride * p.PW + tx * a->stride;
+    };
+    for (int kp = 0; kp < 32; ++kp) d.pe[kp] = (2 * kp < (1 << p.lgNPX)) ? off(2 * kp) : 0;
+    d.po_h = off(1) - off(0);
+  }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ta == 4) fn = wgrad_kernel<4, 4, 1>;
-  else if (p.tb == 2) fn = wgrad_kernel<2, 2, 5>;
-  else fn = wgrad_kernel<2, 1, 4>;
+  if (p.ta == 4) fn = wgrad_kernel<4, 4, 4>;
+  else if (p.tb == 2) fn = wgrad_kernel<2, 2, 9>;
+  else fn = wgrad_kernel<2, 1, 7>;
   if (p.lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, n), dim3(512), p.lds, stream, d);
