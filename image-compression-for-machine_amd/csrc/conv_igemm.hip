@@ -124,12 +124,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
     const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
     PlaneMap pm;
     plane_map_init(pm, pg, n0, iyb, ixb, lane);
-    stage_planes(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
+    stage_planes<12>(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       if (chunk + 1 < nchunks) {
         const int c8 = (chunk + 1) * d.ckm;
-        stage_planes(P.x, pm, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, smem + ((chunk + 1) & 1) * bufsz, lw);
+        stage_planes<12>(P.x, pm, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, smem + ((chunk + 1) & 1) * bufsz, lw);
       }
       __syncthreads();
     }

@@ -13,6 +13,7 @@
 // [a][b][kh][kw] layout by a second kernel: bitwise reproducible, no float atomics (Guideline 12).
 // The bias gradient (row sums of the small-grid tile) is accumulated by the loader waves for free.
 #include <algorithm>
+#include <cmath>
 #include "icm_common.h"
 
 namespace icm {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
         }
         PlaneMap pm;
         plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-        stage_planes(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        stage_planes<12>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
       }
       __syncthreads();
     }
@@ -306,10 +307,18 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
   p.ntiles = p.tiles_x * p.tiles_y * p.tiles_n;
   p.natile = cdiv(a.Ca, 32 * p.ta); p.nbtile = cdiv(a.Cb, 32 * p.tb); p.ngroups = cdiv(ntaps, p.tpg);
   const int base = p.natile * p.nbtile * p.ngroups * std::max(1, nproblems);
-  // whole rounds of workgroups over the 256 CUs (occ per CU by LDS): no tail round, fewest slabs
-  const int occ = std::max<int>(1, (int)((160 * 1024) / p.lds));
-  const int target = 256 * std::min(occ, 2);
-  p.nsplit = std::max(1, std::min(p.ntiles, target / std::max(1, base)));
+  // pixel splits: minimise (rounds of workgroups over the CUs) x (pixel tiles per workgroup + un-overlapped
+  // prologue), with a small charge per split for the extra slab traffic
+  const int occ = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / p.lds)));
+  const double slots = 256.0 * occ;
+  double best = 1e300;
+  p.nsplit = 1;
+  for (int sp = 1; sp <= std::min(p.ntiles, 64); ++sp) {
+    const double rounds = std::ceil((double)base * sp / slots);
+    const double per = (double)cdiv(p.ntiles, sp) + 0.8;
+    const double cost = rounds * per * (1.0 + 0.004 * sp);
+    if (cost < best - 1e-9) { best = cost; p.nsplit = sp; }
+  }
   return ICM_OK;
 }
 

@@ -87,42 +87,44 @@ __device__ __forceinline__ void plane_map_init(PlaneMap& m, const PatchGeom& g, 
 // stage local channels cl = lw, lw+4, ... < nch (global channel c0 + cl) of the patch into dst.
 // NJR = plane slots per lane rounded up to a divisor of 12; 12/NJR channels are in flight together so that a
 // lane always has 12 independent loads outstanding, whatever the plane size.
-template <int NJR>
+template <int NJR, int MJ>
 __device__ __forceinline__ void stage_planes_t(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
                                                int c0, int nch, float* __restrict__ dst, int lw) {
   // lw must be wave-uniform (readfirstlane): channel bases then live in SGPRs and every load is
-  // global_load_dword v, v_off32, s[base] -- no 64-bit vector address arithmetic in the loader
-  constexpr int CPB = ICM_MAXJ / NJR;
+  // global_load_dword v, v_off32, s[base] -- no 64-bit vector address arithmetic in the loader.
+  // MJ = loads in flight per lane (the loaders are latency-bound: L2 / HBM round trips per batch).
+  constexpr int CPB = MJ / NJR;
   const long long HWb = (long long)g.H * g.W * 4;
   const int nk = (nch - lw + 3) >> 2;   // channels of this loader wave
   const char* srcb = reinterpret_cast<const char*>(src);
   char* dstb = reinterpret_cast<char*>(dst);
   for (int kb = 0; kb < nk; kb += CPB) {
-    float v[ICM_MAXJ];
+    float v[CPB * NJR];
 #pragma unroll
-    for (int u = 0; u < ICM_MAXJ; ++u) {
+    for (int u = 0; u < CPB * NJR; ++u) {
       const int k = kb + u / NJR, j = u % NJR;
       const int c = c0 + lw + 4 * k;
       const char* base = srcb + (long long)c * HWb;
       v[u] = (k < nk && c < g.C && m.goff[j] >= 0) ? *reinterpret_cast<const float*>(base + m.goff[j]) : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < ICM_MAXJ; ++u) {
+    for (int u = 0; u < CPB * NJR; ++u) {
       const int k = kb + u / NJR, j = u % NJR;
       if (k < nk && m.loff[j] >= 0)
         *reinterpret_cast<float*>(dstb + (lw + 4 * k) * g.CS * 4 + m.loff[j]) = apply_act(v[u], g.act);
     }
   }
 }
+template <int MJ>
 __device__ __forceinline__ void stage_planes(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
                                              int c0, int nch, float* __restrict__ dst, int lw) {
   const int nj = (g.TIPH * g.PW + 63) >> 6;
-  if (nj <= 1) stage_planes_t<1>(src, m, g, c0, nch, dst, lw);
-  else if (nj == 2) stage_planes_t<2>(src, m, g, c0, nch, dst, lw);
-  else if (nj == 3) stage_planes_t<3>(src, m, g, c0, nch, dst, lw);
-  else if (nj == 4) stage_planes_t<4>(src, m, g, c0, nch, dst, lw);
-  else if (nj <= 6) stage_planes_t<6>(src, m, g, c0, nch, dst, lw);
-  else stage_planes_t<12>(src, m, g, c0, nch, dst, lw);
+  if (nj <= 1) stage_planes_t<1, MJ>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 2) stage_planes_t<2, MJ>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 3) stage_planes_t<3, MJ>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 4) stage_planes_t<4, MJ>(src, m, g, c0, nch, dst, lw);
+  else if (nj <= 6) stage_planes_t<6, MJ>(src, m, g, c0, nch, dst, lw);
+  else stage_planes_t<12, (MJ < 12 ? 12 : MJ)>(src, m, g, c0, nch, dst, lw);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
