@@ -14,24 +14,32 @@ static inline int grid_for(long long n, int per_thread = 4) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------- channel sum: out[c] = sum_{n,p} x[n,c,p]
+// grid (C, S): each workgroup reduces one pixel chunk of one channel and adds its partial with one float atomic
+// (out is zeroed by a memset node first unless accumulating); float4 loads when the plane allows
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long long bs, int N, int C,
-                                                          int HW, float* __restrict__ out, int accum) {
+                                                          int HW, float* __restrict__ out) {
   __shared__ float red[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, S = gridDim.y, sp = blockIdx.y;
   float s = 0.0f;
-  const long long total = (long long)N * HW;
-  for (long long i = threadIdx.x; i < total; i += 256) {
-    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
-    s += x[n * bs + (long long)c * HW + p];
+  if ((HW & 3) == 0 && (bs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int HW4 = HW >> 2;
+    const long long total = (long long)N * HW4;
+    for (long long i = (long long)sp * 256 + threadIdx.x; i < total; i += (long long)S * 256) {
+      const int n = (int)(i / HW4), p = (int)(i - (long long)n * HW4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + n * bs + (long long)c * HW + 4 * p);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    const long long total = (long long)N * HW;
+    for (long long i = (long long)sp * 256 + threadIdx.x; i < total; i += (long long)S * 256) {
+      const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+      s += x[n * bs + (long long)c * HW + p];
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = red[0] + red[1] + red[2] + red[3];
-    if (accum) t += out[c];
-    out[c] = t;
-  }
+  if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
 }
 
 // ---------------------------------------------------------------- NonNegativeParametrizer
@@ -228,7 +236,10 @@ extern "C" {
 
 int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, void* stream) {
   if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, ST, x, (long long)x_bs, N, C, HW, out, accum);
+  if (!accum) hipMemsetAsync(out, 0, (size_t)C * sizeof(float), ST);
+  const long long per_c = (long long)N * HW;
+  const int S = (int)std::max<long long>(1, std::min<long long>(32, per_c / 16384));
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(256), 0, ST, x, (long long)x_bs, N, C, HW, out);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -51,6 +51,45 @@ __device__ __forceinline__ Tok token(const WaDesc& d, int wy, int wx, int j) {
   return t;
 }
 
+// s = sum_d a[d] * row[d]; row is an LDS row shared by all lanes (broadcast): 16-byte reads when HD % 4 == 0
+template <int HD>
+__device__ __forceinline__ float dot_row(const float (&a)[HD], const float* __restrict__ row) {
+  float s = 0.0f;
+  if constexpr (HD % 4 == 0) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+    for (int q = 0; q < HD / 4; ++q) {
+      const f32x4 v = r4[q];
+      s += a[4 * q] * v[0];
+      s += a[4 * q + 1] * v[1];
+      s += a[4 * q + 2] * v[2];
+      s += a[4 * q + 3] * v[3];
+    }
+  } else {
+#pragma unroll
+    for (int dd = 0; dd < HD; ++dd) s += a[dd] * row[dd];
+  }
+  return s;
+}
+// o[d] += p * row[d]
+template <int HD>
+__device__ __forceinline__ void axpy_row(float (&o)[HD], float p, const float* __restrict__ row) {
+  if constexpr (HD % 4 == 0) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+    for (int q = 0; q < HD / 4; ++q) {
+      const f32x4 v = r4[q];
+      o[4 * q] += p * v[0];
+      o[4 * q + 1] += p * v[1];
+      o[4 * q + 2] += p * v[2];
+      o[4 * q + 3] += p * v[3];
+    }
+  } else {
+#pragma unroll
+    for (int dd = 0; dd < HD; ++dd) o[dd] += p * row[dd];
+  }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,9 +126,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
     float m = -3.0e38f;
     if (active) {
       for (int j = 0; j < T; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) s += q[dd] * Ksh[j * HD + dd];
+        float s = dot_row<HD>(q, Ksh + j * HD);
         const Tok tj = token(d, wy, wx, j);
         const int idx = (me.r - tj.r + d.ws - 1) * tw + (me.c - tj.c + d.ws - 1);
         s += d.table[idx * d.heads + head];
@@ -109,8 +146,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
       for (int dd = 0; dd < HD; ++dd) o[dd] = 0.0f;
       for (int j = 0; j < T; ++j) {
         const float p = Ssh[lane * TS + j] * inv;
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) o[dd] += p * Vsh[j * HD + dd];
+        axpy_row<HD>(o, p, Vsh + j * HD);
       }
       float* op = d.out + ((long long)n * d.C + head * HD) * HW;
 #pragma unroll
@@ -126,7 +162,7 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int T = d.T, TS = T + 1;
   const int tw = 2 * d.ws - 1, ntab = tw * tw;
-  const int per_wave = 4 * T * HD + T * TS + ntab;
+  const int per_wave = 4 * T * HD + T * TS + ((ntab + 3) & ~3);   // keep every wave's slab 16-B aligned (b128 reads)
   float* Ksh = smem + wave * per_wave;
   float* Vsh = Ksh + T * HD;
   float* Qsh = Vsh + T * HD;   // scaled q
@@ -168,9 +204,7 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
     if (active) {
       float m = -3.0e38f;
       for (int j = 0; j < T; ++j) {
-        float s = 0.0f;
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) s += q[dd] * Ksh[j * HD + dd];
+        float s = dot_row<HD>(q, Ksh + j * HD);
         const Tok tj = token(d, wy, wx, j);
         const int idx = (me.r - tj.r + d.ws - 1) * tw + (me.c - tj.c + d.ws - 1);
         s += d.table[idx * d.heads + head];
@@ -196,8 +230,7 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
       for (int dd = 0; dd < HD; ++dd) acc[dd] = 0.0f;
       for (int i = 0; i < T; ++i) {
         const float p = Ssh[i * TS + lane];
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) acc[dd] += p * Gsh[i * HD + dd];
+        axpy_row<HD>(acc, p, Gsh + i * HD);
       }
       float* dv = dbase + (long long)(2 * d.C + head * HD) * HW;
 #pragma unroll
@@ -209,22 +242,17 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
     if (active) {
       float delta = 0.0f;
       for (int j = 0; j < T; ++j) {
-        float dp = 0.0f;
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) dp += go[dd] * Vsh[j * HD + dd];
+        const float dp = dot_row<HD>(go, Vsh + j * HD);
         delta += Ssh[lane * TS + j] * dp;
       }
       float dq[HD];
 #pragma unroll
       for (int dd = 0; dd < HD; ++dd) dq[dd] = 0.0f;
       for (int j = 0; j < T; ++j) {
-        float dp = 0.0f;
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) dp += go[dd] * Vsh[j * HD + dd];
+        const float dp = dot_row<HD>(go, Vsh + j * HD);
         const float ds = Ssh[lane * TS + j] * (dp - delta);
         Ssh[lane * TS + j] = ds;
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) dq[dd] += ds * Ksh[j * HD + dd];
+        axpy_row<HD>(dq, ds, Ksh + j * HD);
         const Tok tj = token(d, wy, wx, j);
         const int idx = (me.r - tj.r + d.ws - 1) * tw + (me.c - tj.c + d.ws - 1);
         Bsh[idx] += ds;  // distinct idx across the active lanes of this instruction
@@ -242,8 +270,7 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
       for (int dd = 0; dd < HD; ++dd) acc[dd] = 0.0f;
       for (int i = 0; i < T; ++i) {
         const float ds = Ssh[i * TS + lane];
-#pragma unroll
-        for (int dd = 0; dd < HD; ++dd) acc[dd] += ds * Qsh[i * HD + dd];
+        axpy_row<HD>(acc, ds, Qsh + i * HD);
       }
       float* dk = dbase + (long long)(d.C + head * HD) * HW;
 #pragma unroll
@@ -317,7 +344,7 @@ int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, flo
   if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
   const int waves = std::min(2, heads);
   const int tw = 2 * ws - 1;
-  const size_t lds = (size_t)waves * (4 * d.T * d.hd + d.T * (d.T + 1) + tw * tw) * 4;
+  const size_t lds = (size_t)waves * (4 * d.T * d.hd + d.T * (d.T + 1) + ((tw * tw + 3) & ~3)) * 4;
   if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
