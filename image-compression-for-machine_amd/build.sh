@@ -6,12 +6,15 @@ mkdir -p lib build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 objs=""
+pids=""
 for f in conv_igemm conv_wgrad pointwise entropy winattn; do
   if [ ! -f build/$f.o ] || [ csrc/$f.hip -nt build/$f.o ] || [ csrc/icm_common.h -nt build/$f.o ] || [ ../include/icm_hip.h -nt build/$f.o ]; then
+    rm -f build/$f.o
     $HIPCC $FLAGS -c csrc/$f.hip -o build/$f.o &
+    pids="$pids $!"
   fi
   objs="$objs build/$f.o"
 done
-wait
+for p in $pids; do wait $p || { echo "compile failed"; exit 1; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o lib/libicm_hip.so $objs
 echo "built lib/libicm_hip.so"

@@ -58,6 +58,11 @@ class Tape:
         self._packed: Dict[tuple, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
         self.wjobs: list = []
+        self.side = None          # optional torch.cuda.Stream for deferred wgrads (overlaps the serial dgrad chain)
+        self._side_ws: Optional[torch.Tensor] = None
+        self._flushed: list = []  # keeps side-stream operands alive until the streams are joined
+        self.progress_every = 0
+        self.min_jobs = 8
         self.st = L.stream()
 
     # ---- gradient bookkeeping
@@ -90,10 +95,21 @@ class Tape:
         return self.grads.get(k) if k in self.ready else None
 
     def backward(self):
+        n = 0
         for f in reversed(self.bw):
             f()
+            n += 1
+            if self.progress_every > 0 and n % self.progress_every == 0 and len(self.wjobs) >= self.min_jobs:
+                flush_wgrads(self)
         self.bw = []
         flush_wgrads(self)
+        self.join_side()
+
+    def join_side(self):
+        """main stream waits for everything issued on the side stream"""
+        if self.side is not None and self._flushed:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._flushed = []
 
     # ---- helpers
     def workspace(self, nfloats: int, device) -> torch.Tensor:
@@ -161,13 +177,25 @@ def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE
 
 
 def flush_wgrads(tape):
+    """Issue the queued weight-gradient problems, batched by geometry.  With ``tape.side`` set they go to that
+    stream (after an event on the main stream): nothing on the main stream consumes them before the optimiser,
+    so they fill the CUs the latency-bound dgrad chain leaves idle."""
     if not tape.wjobs:
         return
     groups: Dict[tuple, list] = {}
     for job in tape.wjobs:
         groups.setdefault(job[0], []).append(job)
+    jobs_all = tape.wjobs
     tape.wjobs = []
     lib = L.lib()
+    st = tape.st
+    side = tape.side
+    if side is not None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        side.wait_event(ev)
+        st = side.cuda_stream
+        tape._flushed.append(jobs_all)
     for key, jobs in groups.items():
         Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, gsb, gbb, _ = key
         for i0 in range(0, len(jobs), 32):
@@ -183,10 +211,17 @@ def flush_wgrads(tape):
             if n < 0:
                 raise ValueError("icm wgrad: invalid geometry")
             n = (n + 63) // 64 * 64
-            ws = tape.workspace(n * len(chunk), chunk[0][1].device)
+            if side is not None:
+                if tape._side_ws is None or tape._side_ws.numel() < n * len(chunk):
+                    with torch.cuda.stream(side):
+                        tape._side_ws = torch.empty(max(n * len(chunk), 1 << 24), dtype=torch.float32,
+                                                    device=chunk[0][1].device)
+                ws = tape._side_ws
+            else:
+                ws = tape.workspace(n * len(chunk), chunk[0][1].device)
             for j, a in enumerate(arr):
                 a.ws = ptr(ws) + 4 * n * j
-            check(lib.icm_conv_wgrad_grouped(arr, len(chunk), tape.st), "conv_wgrad_grouped")
+            check(lib.icm_conv_wgrad_grouped(arr, len(chunk), st), "conv_wgrad_grouped")
 
 
 def accumulate(tape, dst_t, src, mul_dgelu_of=None):

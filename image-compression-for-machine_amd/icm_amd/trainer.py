@@ -138,6 +138,12 @@ class Trainer:
         self.step_no = 0
         self.names = [n for n, _ in self.flat.main] + [n for n, _ in self.flat.aux]
         self.scal = torch.zeros(8, dtype=torch.float32, device=self.device)  # [0:5] rd loss, [5] sqnorm, [6] aux
+        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._side_ws = None
+        import os as _os
+        self.wg_every = int(_os.environ.get("ICM_WG_EVERY", "24"))
+        if self.wg_every < 0:
+            self.side = None
         self._eb = None
 
     def params(self) -> Dict[str, torch.Tensor]:
@@ -158,6 +164,7 @@ class Trainer:
             nz, ny = noise["z"].to(dev).contiguous(), noise["y"].to(dev).contiguous()
         P = f.views
         tape = E.Tape(need_grad=True)
+        tape.side, tape._side_ws, tape.progress_every = self.side, self._side_ws, self.wg_every
         tape.stop(x)
         for n, _ in f.main:
             tape.bind_grad(P[n], f.gviews[n], False)
@@ -175,8 +182,9 @@ class Trainer:
         tape.bind_grad(z_lik, dlz, True)
         # ---- backward with bucketed all-reduce overlapped (markers fire as the tape unwinds)
         for name, idx in sorted(marks.items(), key=lambda kv: -kv[1]):
-            tape.bw.insert(idx, (lambda b=name: (E.flush_wgrads(tape), self.reducer.launch(b))))
+            tape.bw.insert(idx, (lambda b=name: (E.flush_wgrads(tape), tape.join_side(), self.reducer.launch(b))))
         tape.backward()
+        self._side_ws = tape._side_ws
         self.reducer.launch(len(BUCKETS) - 1)   # g_a: last gradients to complete
         if len(f.bucket_ranges) > len(BUCKETS):
             self.reducer.launch(len(BUCKETS))
