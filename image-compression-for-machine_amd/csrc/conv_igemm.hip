@@ -285,6 +285,35 @@ __global__ void pack_weights_kernel(const PackDesc d) {
   }
 }
 
+#define ICM_PACK_NB 24
+struct PackMulti {
+  PackDesc g[ICM_PACK_NB];
+};
+__global__ void pack_weights_multi_kernel(const PackMulti m) {
+  const PackDesc& d = m.g[blockIdx.y];
+  const long long total = (long long)d.nchunks * d.ntaps * d.ncot * 256;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    long long q = i >> 8;
+    const int cot = (int)(q % d.ncot);
+    q /= d.ncot;
+    const int t = (int)(q % d.ntaps);
+    const int chunk = (int)(q / d.ntaps);
+    const int co = cot * 32 + (lane & 31), ci = chunk * 8 + 2 * j + (lane >> 5);
+    float v = 0.0f;
+    if (co < d.Co && ci < d.Ci) {
+      const long long src = d.src_out_major ? ((long long)co * d.Ci + ci) : ((long long)ci * d.Co + co);
+      v = d.w[src * d.KHW + d.tapidx[t]];
+      if (d.nonneg) {
+        v = fmaxf(v, d.bound);
+        v = v * v - d.pedestal;
+      }
+    }
+    d.wp[i] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------- host planning
 struct Tap {
   int kidx;    // kh*KW + kw in the canonical weight
@@ -581,6 +610,48 @@ int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int K
     off += total;
   }
   return ICM_OK;
+}
+
+
+int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
+  using namespace icm;
+  if (!jobs || n < 1) return ICM_ERR_ARG;
+  PackMulti m;
+  int nb = 0;
+  auto flush = [&]() -> int {
+    if (nb == 0) return ICM_OK;
+    for (int i = nb; i < ICM_PACK_NB; ++i) m.g[i] = m.g[0];
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(48, nb), dim3(256), 0, (hipStream_t)stream, m);
+    ICM_CHECK_LAUNCH();
+    nb = 0;
+    return ICM_OK;
+  };
+  for (int k = 0; k < n; ++k) {
+    const icm_pack_job& J = jobs[k];
+    if (!J.w || !J.wp || J.Cout <= 0 || J.Cin <= 0 || J.KH * J.KW > ICM_MAX_TAPS || (J.stride != 1 && J.stride != 2))
+      return ICM_ERR_ARG;
+    std::vector<ConvClass> classes = build_classes(J.KH, J.KW, J.stride, J.pad, J.transposed);
+    const int ncot = cdiv(J.Cout, 32), nchunks = cdiv(J.Cin, 8);
+    long long off = 0;
+    for (const ConvClass& cls : classes) {
+      const int ntaps = (int)cls.taps.size();
+      if (ntaps == 0) continue;
+      PackDesc& d = m.g[nb];
+      d.w = J.w;
+      d.wp = J.wp + off;
+      d.Co = J.Cout; d.Ci = J.Cin; d.KHW = J.KH * J.KW; d.src_out_major = J.src_out_major;
+      d.ntaps = ntaps; d.ncot = ncot; d.nchunks = nchunks; d.nonneg = J.nonneg;
+      d.bound = J.bound; d.pedestal = J.pedestal;
+      for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
+      for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
+      off += (long long)nchunks * ntaps * ncot * 256;
+      if (++nb == ICM_PACK_NB) {
+        int rc = flush();
+        if (rc) return rc;
+      }
+    }
+  }
+  return flush();
 }
 
 }  // extern "C"

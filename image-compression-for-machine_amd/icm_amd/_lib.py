@@ -42,6 +42,11 @@ class WgradArgs(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("w", vp), ("wp", vp), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32), ("src_out_major", i32),
+                ("transposed", i32), ("stride", i32), ("pad", i32), ("nonneg", i32), ("bound", f32), ("pedestal", f32)]
+
+
 class EbParams(C.Structure):
     _fields_ = [("matrix", vp * 5), ("bias", vp * 5), ("factor", vp * 4), ("quantiles", vp)]
 
@@ -59,7 +64,7 @@ _lib = None
 # every symbol include/icm_hip.h declares (tests check that the .so exports them all)
 SYMBOLS = [
     "icm_strerror", "icm_version", "icm_conv_run", "icm_conv_run_grouped", "icm_conv2d_fwd", "icm_conv2d_dgrad",
-    "icm_convT2d_fwd", "icm_convT2d_dgrad", "icm_packed_weight_floats", "icm_pack_weights",
+    "icm_convT2d_fwd", "icm_convT2d_dgrad", "icm_packed_weight_floats", "icm_pack_weights", "icm_pack_weights_batch",
     "icm_wgrad_workspace_floats", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
@@ -81,6 +86,7 @@ def lib():
         L.icm_wgrad_workspace_floats.restype = i64
         L.icm_packed_weight_floats.argtypes = [i32, i32, i32, i32]
         L.icm_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]
+        L.icm_pack_weights_batch.argtypes = [C.POINTER(PackJob), i32, vp]
         L.icm_conv_run.argtypes = [C.POINTER(ConvArgs), vp]
         L.icm_conv_run_grouped.argtypes = [C.POINTER(ConvArgs), i32, vp]
         for n in ("icm_conv2d_fwd", "icm_conv2d_dgrad", "icm_convT2d_fwd", "icm_convT2d_dgrad"):

@@ -58,6 +58,7 @@ class Tape:
         self._packed: Dict[tuple, torch.Tensor] = {}
         self._ws: Optional[torch.Tensor] = None
         self.wjobs: list = []
+        self.pack_log = None      # when a list: records (w, args) of every cache miss (the trainer's packing plan)
         self.side = None          # optional torch.cuda.Stream for deferred wgrads (overlaps the serial dgrad chain)
         self._side_ws: Optional[torch.Tensor] = None
         self._flushed: list = []  # keeps side-stream operands alive until the streams are joined
@@ -117,9 +118,29 @@ class Tape:
             self._ws = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
         return self._ws
 
+    def prepack(self, plan, store):
+        """Issue every packing job of a recorded plan (list of (w, args)) as batched launches into persistent
+        buffers ``store`` and seed the cache, so the per-layer pack() calls of this step are all hits."""
+        if not plan:
+            return
+        jobs = (L.PackJob * len(plan))()
+        for j, (w, a) in zip(jobs, plan):
+            M, K, KH, KW, som, tr, stride, pad, nonneg, bound, ped = a
+            key = (w.data_ptr(), w._version, M, K, KH, KW, som, tr, stride, pad, nonneg)
+            wp = store.get(key)
+            if wp is None:
+                wp = torch.empty(L.lib().icm_packed_weight_floats(M, K, KH, KW), dtype=torch.float32, device=w.device)
+                store[key] = wp
+            j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w), ptr(wp), M, K, KH, KW
+            j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal = som, tr, stride, pad, nonneg, bound, ped
+            self._packed[key] = wp
+        check(L.lib().icm_pack_weights_batch(jobs, len(plan), self.st), "pack_weights_batch")
+
     def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0):
         k = (w.data_ptr(), w._version, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg)
         wp = self._packed.get(k)
+        if wp is None and self.pack_log is not None:
+            self.pack_log.append((w, (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg, bound, ped)))
         if wp is None:
             n = L.lib().icm_packed_weight_floats(M, K, KH, KW)
             wp = torch.empty(n, dtype=torch.float32, device=w.device)

@@ -90,6 +90,14 @@ int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int K
                      int transposed, int stride, int pad, int nonneg, float bound, float pedestal,
                      void* stream);
 
+/* many packing jobs in few launches (the trainer re-packs every weight once per step, forward and dgrad forms) */
+typedef struct icm_pack_job {
+  const float* w; float* wp;
+  int Cout, Cin, KH, KW, src_out_major, transposed, stride, pad, nonneg;
+  float bound, pedestal;
+} icm_pack_job;
+int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream);
+
 /* weight gradient: dW[a][b][t] = sum_{n,p} actS(gs[n,a,p]) * actB(gb[n,b,p*stride - pad + t])
  * conv:  gs = dY (a = Cout), gb = x  (b = Cin) -> Conv2d.weight.grad
  * convT: gs = x  (a = Cin),  gb = dY (b = Cout) -> ConvTranspose2d.weight.grad
