@@ -102,6 +102,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(WCO * WPX == 4, "4 MFMA waves per workgroup");
   constexpr int BCO_T = WCO * TCO;
+  // small tiles: pipeline steps of TS (8-channel group, tap) sub-steps so that a step carries >= 8-12 MFMAs
+  constexpr int TS = (TCO * TPX == 1) ? 3 : ((TCO * TPX == 2) ? 2 : 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool loader = wave >= 4;
   const ConvPtrs P = d.g[blockIdx.y];
@@ -163,74 +165,168 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
   for (int a = 0; a < TCO; ++a) wl[a] = min(cot0 + a, d.ncot - 1) * 64 + lane;
   const int qstride = d.ncot * 64;             // f32x4 elements between consecutive (chunk8, tap) steps
   const int Qtot = d.nchunks8 * d.ntaps;
-  int Q = 0;
-  f32x4 a_nxt[TCO];
-#pragma unroll
-  for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[wl[a]];
-
-  const int toff_lane = d.tapoff[lane & 31];   // tap offsets live in one VGPR; v_readlane picks entry t
-  __syncthreads();  // patch of chunk 0 staged
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const float* cur = smem + (chunk & 1) * bufsz;
-    const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
-    const int nq = nsub * d.ntaps;
-    // software pipeline over (8-channel group, tap) steps, branch-free so that each step is one basic block:
-    // B fragments of step q+1 are read from LDS and A fragments (weights) of step Q+1 from L2 while the MFMAs of
-    // step q issue; the last step of a chunk re-reads its own fragments
-    float bv_n[4][TPX];
+  if constexpr (TS > 1) {
+    // LDS offset of sub-step q of a chunk (8-channel group q / ntaps, tap q % ntaps) lives in lane q of one VGPR:
+    // v_readlane replaces the scalar (group, tap) bookkeeping; the host guarantees ckm * ntaps <= 64
+    int step_lane;
     {
-      const float* bp = cur + __builtin_amdgcn_readlane(toff_lane, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
+      const int sq = lane / d.ntaps, tq = lane - sq * d.ntaps;
+      step_lane = sq * 8 * pg.CS + d.tapoff[tq];
     }
-    int sub = 0, t = 0;
-    for (int q = 0; q < nq; ++q) {
-      f32x4 a_cur[TCO];
-      float bv[4][TPX];
+
+    f32x4 a_n[TS][TCO];   // weights of the next step; prefetched across chunk boundaries (they do not live in LDS)
 #pragma unroll
-      for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
+    for (int u = 0; u < TS; ++u)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int a = 0; a < TCO; ++a) a_n[u][a] = wp4[(long long)min(u, Qtot - 1) * qstride + wl[a]];
+
+    __syncthreads();  // patch of chunk 0 staged
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const float* cur = smem + (chunk & 1) * bufsz;
+      const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
+      const int nq = nsub * d.ntaps;
+      const int Qbase = chunk * d.ckm * d.ntaps;
+      const int nsteps = (nq + TS - 1) / TS;
+      // Software pipeline over steps of TS (8-channel group, tap) sub-steps, branch-free so that a step is one
+      // basic block: the fragments of step s+1 (B from LDS, A = packed weights from L2) are fetched in the
+      // shadows of step s's MFMAs.  Small tiles take TS > 1 so that a step carries >= 8-12 MFMAs: the wave issues
+      // in order, and whatever trails the last MFMA of a step runs with the matrix pipe idle.
+      float bv_n[TS][4][TPX];
 #pragma unroll
-        for (int tp = 0; tp < TPX; ++tp) bv[j][tp] = bv_n[j][tp];
-      Q = min(Q + 1, Qtot - 1);
+      for (int u = 0; u < TS; ++u) {
+        const int qc = min(u, nq - 1);
+        const float okf = (u < nq) ? 1.0f : 0.0f;
+        const float* bp = cur + __builtin_amdgcn_readlane(step_lane, qc);
 #pragma unroll
-      for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(long long)Q * qstride + wl[a]];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int tp = 0; tp < TPX; ++tp) bv_n[u][j][tp] = bp[boff[tp] + 2 * j * pg.CS] * okf;
+      }
+      for (int st = 0; st < nsteps; ++st) {
+        f32x4 a_c[TS][TCO];
+        float bv[TS][4][TPX];
+#pragma unroll
+        for (int u = 0; u < TS; ++u) {
+#pragma unroll
+          for (int a = 0; a < TCO; ++a) a_c[u][a] = a_n[u][a];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < TPX; ++tp) bv[u][j][tp] = bv_n[u][j][tp];
+        }
+        const int sn = min(st + 1, nsteps - 1);
+#pragma unroll
+        for (int u = 0; u < TS; ++u) {
+          const int qq = sn * TS + u;
+          const int qc = min(qq, nq - 1);
+          const float* bp = cur + __builtin_amdgcn_readlane(step_lane, qc);
+          const float okf = (qq < nq) ? 1.0f : 0.0f;   // sub-steps past the chunk contribute zero
+          // last step of the chunk: fetch the first step of the NEXT chunk instead (Q is contiguous across chunks)
+          const int qw = (st + 1 < nsteps) ? Qbase + qc : min(Qbase + nq + u, Qtot - 1);
+#pragma unroll
+          for (int a = 0; a < TCO; ++a) a_n[u][a] = wp4[(long long)qw * qstride + wl[a]];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < TPX; ++tp) {
+              const float v = bp[boff[tp] + 2 * j * pg.CS];
+              bv_n[u][j][tp] = (TS == 1) ? v : v * okf;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TS; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TCO; ++a)
+#pragma unroll
+              for (int tp = 0; tp < TPX; ++tp)
+                acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[u][a][j], bv[u][j][tp], acc[a][tp], 0, 0, 0);
+        // issue order: after each MFMA (64 cycles of matrix pipe) slot in one fragment fetch of the NEXT step
+#pragma unroll
+        for (int m = 0; m < TS * 4 * TCO * TPX; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (m < TS * TCO) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (m < TS * 4 * TPX) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+  } else {
+    int Q = 0;
+    f32x4 a_nxt[TCO];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[wl[a]];
+
+    const int toff_lane = d.tapoff[lane & 31];   // tap offsets live in one VGPR; v_readlane picks entry t
+    __syncthreads();  // patch of chunk 0 staged
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const float* cur = smem + (chunk & 1) * bufsz;
+      const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
+      const int nq = nsub * d.ntaps;
+      // software pipeline over (8-channel group, tap) steps, branch-free so that each step is one basic block:
+      // B fragments of step q+1 are read from LDS and A fragments (weights) of step Q+1 from L2 while the MFMAs of
+      // step q issue; the last step of a chunk re-reads its own fragments
+      float bv_n[4][TPX];
       {
-        const bool last = q + 1 == nq;
-        int tn = t + 1, subn = sub;
-        const bool wrap = tn == d.ntaps;
-        tn = wrap ? 0 : tn;
-        subn = wrap ? sub + 1 : sub;
-        t = last ? t : tn;
-        sub = last ? sub : subn;
-        const float* bp = cur + sub * 8 * pg.CS + __builtin_amdgcn_readlane(toff_lane, t);
+        const float* bp = cur + __builtin_amdgcn_readlane(toff_lane, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
       }
+      int sub = 0, t = 0;
+      for (int q = 0; q < nq; ++q) {
+        f32x4 a_cur[TCO];
+        float bv[4][TPX];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
 #pragma unroll
-        for (int a = 0; a < TCO; ++a)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int tp = 0; tp < TPX; ++tp)
-            acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[j][tp], acc[a][tp], 0, 0, 0);
-      // issue order: after each MFMA (64 cycles of matrix pipe) slot in one fragment fetch of the NEXT step
+          for (int tp = 0; tp < TPX; ++tp) bv[j][tp] = bv_n[j][tp];
+        Q = min(Q + 1, Qtot - 1);
 #pragma unroll
-      for (int m = 0; m < 4 * TCO * TPX; ++m) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (m < TCO) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if (m < 4 * TPX) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(long long)Q * qstride + wl[a]];
+        {
+          const bool last = q + 1 == nq;
+          int tn = t + 1, subn = sub;
+          const bool wrap = tn == d.ntaps;
+          tn = wrap ? 0 : tn;
+          subn = wrap ? sub + 1 : sub;
+          t = last ? t : tn;
+          sub = last ? sub : subn;
+          const float* bp = cur + sub * 8 * pg.CS + __builtin_amdgcn_readlane(toff_lane, t);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int a = 0; a < TCO; ++a)
+#pragma unroll
+            for (int tp = 0; tp < TPX; ++tp)
+              acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[j][tp], acc[a][tp], 0, 0, 0);
+        // issue order: after each MFMA (64 cycles of matrix pipe) slot in one fragment fetch of the NEXT step
+#pragma unroll
+        for (int m = 0; m < 4 * TCO * TPX; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (m < TCO) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          if (m < 4 * TPX) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
+
   }
 
   // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h
@@ -422,6 +518,7 @@ static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, i
   // round trips and the barrier itself stay hidden, within 64 KB of LDS for the two buffers
   int ckm = cdiv(256, ntaps * 4 * tiles_per_wave);
   ckm = std::max(1, std::min(ckm, nchunks8));
+  if (tiles_per_wave <= 2) ckm = std::max(1, std::min(ckm, 64 / std::max(1, ntaps)));   // step table = one VGPR
   while (ckm > 1 && (size_t)2 * ckm * 8 * g.CS * sizeof(float) > 64 * 1024) --ckm;
   g.ckm = ckm;
   g.lds_bytes = (size_t)2 * ckm * 8 * g.CS * sizeof(float);

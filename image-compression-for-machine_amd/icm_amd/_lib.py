@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libicm_hip.so")
+LIB_PATH = os.environ.get("ICM_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libicm_hip.so"))
 
 ACT_NONE, ACT_GELU, ACT_SQUARE = 0, 1, 2
 EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_GDN, EPI_IGDN, EPI_MUL_DGELU, EPI_AXPY2, EPI_LRP = range(8)
