@@ -47,10 +47,19 @@ def dominant_kernel_roofline(dev, iters=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flop = 2.0 * BATCH_PER_GPU * 192 * 192 * 25 * 64 * 64
+    # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    # runs, FETCH_SIZE doubled per the gfx950 correction): tools/pmc_dominant.sh -> profiles/r01_pmc_dominant.json.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     return {"bound": "mfma", "kernel": "conv_igemm_kernel (g_a.2 fwd: conv5x5 s2 192->192 @ [16,192,128,128])",
             "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms,
-            "algorithmic_flop_per_launch": flop}
+            "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "traffic_note": "HBM bytes/launch from committed PMC passes (not re-measured in this run)",
+            "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop}
 
 
 def cpu_baseline(sd_cpu, threads):

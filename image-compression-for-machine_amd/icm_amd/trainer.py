@@ -141,7 +141,8 @@ class Trainer:
         self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._side_ws = None
         import os as _os
-        self.wg_every = int(_os.environ.get("ICM_WG_EVERY", "24"))
+        self.wg_every = int(_os.environ.get("ICM_WG_EVERY", "8"))
+        self.wg_min = int(_os.environ.get("ICM_WG_MIN", "8"))
         if self.wg_every < 0:
             self.side = None
         self._eb = None
@@ -165,6 +166,7 @@ class Trainer:
         P = f.views
         tape = E.Tape(need_grad=True)
         tape.side, tape._side_ws, tape.progress_every = self.side, self._side_ws, self.wg_every
+        tape.min_jobs = self.wg_min
         tape.stop(x)
         # Weights are packed just in time (Tape.pack), right before the GEMM that reads them: measured on MI355X,
         # packing all 600 MB up front (icm_pack_weights_batch) is 8 % slower end to end -- the packed fragments
