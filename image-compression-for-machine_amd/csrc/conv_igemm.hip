@@ -125,6 +125,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
   if (loader) {
     const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
     PlaneMap pm;
+    if (pg.vec4) {
+      plane_map_init_v4(pm, pg, n0, iyb, ixb, lane);
+      stage_planes_v4<8>(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
+      __syncthreads();
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 < nchunks) {
+          const int c8 = (chunk + 1) * d.ckm;
+          stage_planes_v4<8>(P.x, pm, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, smem + ((chunk + 1) & 1) * bufsz,
+                             lw);
+        }
+        __syncthreads();
+      }
+      return;
+    }
     plane_map_init(pm, pg, n0, iyb, ixb, lane);
     stage_planes<12>(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
     __syncthreads();
@@ -582,6 +596,15 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   pg.dTIPH = make_fastdiv((uint32_t)pg.TIPH);
   pg.dPH = make_fastdiv((uint32_t)bg.PH);
   pg.H = a.H; pg.W = a.W; pg.N = a.N; pg.C = a.Cin; pg.act = a.pro_act; pg.bs = a.x_bs;
+  {
+    const int TW = 1 << bg.lgTW;
+    const int plane4 = (1 << bg.lgTI) * bg.PH * (bg.PW / 4);
+    bool v4 = S_in == 1 && cls.ex == 1 && cls.ey == 1 && cls.ix0 == 0 && (bg.PW % 4) == 0 && (TW % 4) == 0 &&
+              (a.W % 4) == 0 && (a.x_bs % 4) == 0 && ((long long)a.H * a.W % 4) == 0 && plane4 <= 4 * 64 &&
+              (bg.CS % 4) == 0 && (bg.PWrow % 4) == 0 && (bg.PP % 4) == 0;
+    for (int gi = 0; gi < ngroups; ++gi) v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[gi].x) & 15) == 0);
+    pg.vec4 = v4 ? 1 : 0;
+  }
   d.Cout = a.Cout;
   d.ps2 = a.pixel_shuffle == 2;
   d.OHf = d.ps2 ? a.OH * 2 : a.OH;

@@ -33,7 +33,7 @@ struct WgDesc {
   PatchGeom pg;      // big-grid tensor + patch layout (identity colmap)
   int Ca, OH, OW, act_s;
   int S, pad, ntaps, tpg;   // taps per tap-group
-  int lgTW, lgTH, lgTI, lgNPX;
+  int lgTW, lgTH, lgTI, lgNPX, gs_vec4;
   int tiles_x, tiles_y, tiles_n, ntiles, nsplit;
   int natile, nbtile, ngroups;
   int po_h;                    // patch offset of pixel 2kp+1 relative to pixel 2kp
@@ -82,6 +82,30 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
         float* gbP = gsT + gs_sz;
         const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
         const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
+        if (d.gs_vec4) {
+          // 16-byte loads: lane handles 4 consecutive pixels of channel (ltid >> 4) + 16k
+          const int p4 = (ltid & 15) << 2;
+          const int tx4 = p4 & TWm, ty4 = (p4 >> d.lgTW) & THm, ti4 = p4 >> (d.lgTW + d.lgTH);
+          const int n4 = n0 + ti4, oy4 = oy0 + ty4, ox4 = ox0 + tx4;
+          const bool pv4 = n4 < pg.N && oy4 < d.OH && ox4 < d.OW;
+          const float* src4 = G.gs + (long long)n4 * d.gs_bs + oy4 * d.OW + ox4;
+          const int a_sub4 = ltid >> 4;
+#pragma unroll
+          for (int k = 0; k < TA * 2; ++k) {
+            const int a = a_sub4 + 16 * k, ca = a0 + a;
+            f32x4 v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (pv4 && ca < d.Ca) v = *reinterpret_cast<const f32x4*>(src4 + (long long)ca * OHW);
+            float* dst = gsT + a * grow + p4;
+            float s4 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float w = apply_act(v[e], d.act_s);
+              dst[e] = w;
+              s4 += w;
+            }
+            bsum[k] += s4;
+          }
+        } else {
         const float* src = G.gs + (long long)n * d.gs_bs + oy * d.OW + ox;
 #pragma unroll
         for (int k = 0; k < TA * 8; ++k) {
@@ -96,13 +120,27 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
             bsum[k] += v;
           }
         }
+        }
         PlaneMap pm;
-        plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-        stage_planes<12>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        if (pg.vec4) {
+          plane_map_init_v4(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+          stage_planes_v4<8>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        } else {
+          plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+          stage_planes<12>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        }
       }
       __syncthreads();
     }
-    if (do_bias) {
+    if (do_bias && d.gs_vec4) {
+#pragma unroll
+      for (int k = 0; k < TA * 2; ++k) {
+        float s = bsum[k];
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const int a = (ltid >> 4) + 16 * k, ca = a0 + a;
+        if ((ltid & 15) == 0 && ca < d.Ca) G.dbias_ws[(long long)split * d.Ca + ca] = s;
+      }
+    } else if (do_bias) {
 #pragma unroll
       for (int k = 0; k < TA * 8; ++k) {
         float s = bsum[k];
@@ -367,6 +405,19 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   pg.dTIPH = make_fastdiv((uint32_t)pg.TIPH);
   pg.dPH = make_fastdiv((uint32_t)p.PH);
   pg.H = a->H; pg.W = a->W; pg.N = a->N; pg.C = a->Cb; pg.act = a->act_b; pg.bs = a->gb_bs;
+  {
+    const int TW = 1 << p.lgTW;
+    bool v4 = ntaps == 1 && a->stride == 1 && a->pad == 0 && p.lgNPX == 6 && (TW % 4) == 0 && (a->W % 4) == 0 &&
+              (a->gb_bs % 4) == 0 && ((long long)a->H * a->W % 4) == 0 && (p.PW % 4) == 0 && (p.PP % 4) == 0;
+    bool g4 = p.lgNPX == 6 && (TW % 4) == 0 && (a->OW % 4) == 0 && (a->gs_bs % 4) == 0 &&
+              ((long long)a->OH * a->OW % 4) == 0;
+    for (int i = 0; i < n; ++i) {
+      v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[i].gb) & 15) == 0);
+      g4 = g4 && ((reinterpret_cast<uintptr_t>(arr[i].gs) & 15) == 0);
+    }
+    pg.vec4 = v4 ? 1 : 0;
+    d.gs_vec4 = g4 ? 1 : 0;
+  }
   d.Ca = a->Ca; d.OH = a->OH; d.OW = a->OW; d.act_s = a->act_s;
   d.S = a->stride; d.pad = a->pad; d.ntaps = ntaps; d.tpg = p.tpg;
   d.lgTW = p.lgTW; d.lgTH = p.lgTH; d.lgTI = p.lgTI; d.lgNPX = p.lgNPX;

@@ -54,6 +54,7 @@ struct PatchGeom {
   FastDiv dPW, dTIPH, dPH;
   int H, W, N, C, act;
   long long bs;
+  int vec4;   // halo-free, 4-pixel-aligned patch: stage with 16-byte loads / LDS stores (host-checked)
 };
 // Plane-sweep staging: a loader wave owns whole channels; its 64 lanes sweep the (TI x PH x PW) plane of the
 // patch linearly.  The per-lane plane offsets (global and LDS) depend only on the tile, so they are computed
@@ -87,6 +88,74 @@ __device__ __forceinline__ void plane_map_init(PlaneMap& m, const PatchGeom& g, 
 // stage local channels cl = lw, lw+4, ... < nch (global channel c0 + cl) of the patch into dst.
 // NJR = plane slots per lane rounded up to a divisor of 12; 12/NJR channels are in flight together so that a
 // lane always has 12 independent loads outstanding, whatever the plane size.
+// ---- 16-byte variant for halo-free patches (1x1 convolutions / Linear layers): PW, W, the patch origin and
+// all strides are multiples of 4 pixels, so a lane moves 4 consecutive pixels per load and per LDS store.
+__device__ __forceinline__ void plane_map_init_v4(PlaneMap& m, const PatchGeom& g, int n0, int iyb, int ixb, int lane) {
+  const int pw4 = g.PW >> 2;
+  const int plane4 = g.TIPH * pw4;
+#pragma unroll
+  for (int j = 0; j < ICM_MAXJ; ++j) {
+    const int e = lane + 64 * j;
+    m.goff[j] = -1;
+    m.loff[j] = -1;
+    if (e < plane4) {
+      const int r = e / pw4;
+      const int px = (e - r * pw4) << 2;
+      const int ti = r / g.PH;
+      const int py = r - ti * g.PH;
+      const int n = n0 + ti, iy = iyb + py, ix = ixb + px;
+      if (n < g.N && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+        m.goff[j] = ((int)((long long)n * g.bs) + iy * g.W + ix) * 4;
+      m.loff[j] = (ti * g.PP + py * g.PWrow + px) * 4;
+    }
+  }
+}
+template <int NJR, int MJ>
+__device__ __forceinline__ void stage_planes_t_v4(const float* __restrict__ src, const PlaneMap& m,
+                                                  const PatchGeom& g, int c0, int nch, float* __restrict__ dst,
+                                                  int lw) {
+  constexpr int CPB = MJ / NJR;
+  const long long HWb = (long long)g.H * g.W * 4;
+  const int nk = (nch - lw + 3) >> 2;
+  const char* srcb = reinterpret_cast<const char*>(src);
+  char* dstb = reinterpret_cast<char*>(dst);
+  for (int kb = 0; kb < nk; kb += CPB) {
+    f32x4 v[CPB * NJR];
+#pragma unroll
+    for (int u = 0; u < CPB * NJR; ++u) {
+      const int k = kb + u / NJR, j = u % NJR;
+      const int c = c0 + lw + 4 * k;
+      const char* base = srcb + (long long)c * HWb;
+      if (k < nk && c < g.C && m.goff[j] >= 0) v[u] = *reinterpret_cast<const f32x4*>(base + m.goff[j]);
+      else v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int u = 0; u < CPB * NJR; ++u) {
+      const int k = kb + u / NJR, j = u % NJR;
+      if (k < nk && m.loff[j] >= 0) {
+        f32x4 w;
+        w[0] = apply_act(v[u][0], g.act); w[1] = apply_act(v[u][1], g.act);
+        w[2] = apply_act(v[u][2], g.act); w[3] = apply_act(v[u][3], g.act);
+        char* o = dstb + (lw + 4 * k) * g.CS * 4 + m.loff[j];
+        if ((g.CS & 3) == 0) {
+          *reinterpret_cast<f32x4*>(o) = w;
+        } else {   // odd channel stride (conflict-free wgrad B fragments): four dword stores
+          float* of = reinterpret_cast<float*>(o);
+          of[0] = w[0]; of[1] = w[1]; of[2] = w[2]; of[3] = w[3];
+        }
+      }
+    }
+  }
+}
+template <int MJ>
+__device__ __forceinline__ void stage_planes_v4(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
+                                                int c0, int nch, float* __restrict__ dst, int lw) {
+  const int nj = (g.TIPH * (g.PW >> 2) + 63) >> 6;
+  if (nj <= 1) stage_planes_t_v4<1, MJ>(src, m, g, c0, nch, dst, lw);
+  else if (nj == 2) stage_planes_t_v4<2, MJ>(src, m, g, c0, nch, dst, lw);
+  else stage_planes_t_v4<4, MJ>(src, m, g, c0, nch, dst, lw);   // host guarantees nj <= 4 when vec4 is set
+}
+
 template <int NJR, int MJ>
 __device__ __forceinline__ void stage_planes_t(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
                                                int c0, int nch, float* __restrict__ dst, int lw) {
