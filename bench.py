@@ -97,11 +97,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    # rehearsal on a one-GPU box: ICM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend
+    share = os.environ.get("ICM_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
     from icm_amd.zoo import models
     from icm_amd.trainer import Trainer
     torch.manual_seed(0)
@@ -135,7 +139,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev)
+        t = torch.tensor([dt], device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     if rank == 0:

@@ -109,6 +109,13 @@ class GradReducer:
         if b <= a:
             return
         t = self.g[a:b]
+        if self.cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal path (several ranks sharing one GPU): stage through the host
+            torch.cuda.current_stream().synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
