@@ -147,6 +147,117 @@ __global__ void pixel_unshuffle2_kernel(const float* src, float* dst, int N, int
     dst[i] = src[(((long long)b * C + c) * (2 * H) + 2 * y + dy) * (2 * W) + 2 * x + dx];
   }
 }
+// ---------------------------------------------------------------- LayerNorm over channels on NCHW (stf.py: nn.LayerNorm(C) on tokens)
+// thread = pixel; channel loop strides by HW so every load/store is coalesced across the wave
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ y, long long ybs,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int N, int C, int HW,
+                                     float eps) {
+  const long long total = (long long)N * HW;
+  GRID_STRIDE(i, total) {
+    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+    const float* xp = x + n * xbs + p;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += xp[(long long)c * HW];
+    const float m = s / (float)C;
+    float v = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float d = xp[(long long)c * HW] - m;
+      v += d * d;
+    }
+    const float r = rsqrtf(v / (float)C + eps);
+    if (mean) { mean[i] = m; rstd[i] = r; }
+    float* yp = y + n * ybs + p;
+    for (int c = 0; c < C; ++c) yp[(long long)c * HW] = (xp[(long long)c * HW] - m) * r * gamma[c] + beta[c];
+  }
+}
+// dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))
+__global__ void layernorm_bwd_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ dy,
+                                     long long dbs, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, float* __restrict__ dx, long long dxbs, int N,
+                                     int C, int HW, int accum) {
+  const long long total = (long long)N * HW;
+  GRID_STRIDE(i, total) {
+    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+    const float* xp = x + n * xbs + p;
+    const float* gp = dy + n * dbs + p;
+    const float m = mean[i], r = rstd[i];
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      const float gg = gp[(long long)c * HW] * gamma[c];
+      s1 += gg;
+      s2 += gg * (xp[(long long)c * HW] - m) * r;
+    }
+    s1 /= (float)C;
+    s2 /= (float)C;
+    float* dp = dx + n * dxbs + p;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (xp[(long long)c * HW] - m) * r;
+      float v = r * (gp[(long long)c * HW] * gamma[c] - s1 - xh * s2);
+      if (accum) v += dp[(long long)c * HW];
+      dp[(long long)c * HW] = v;
+    }
+  }
+}
+// dgamma[c] = sum_{n,p} dy * xhat ; dbeta[c] = sum dy   (one workgroup per channel)
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, long long xbs,
+                                                                   const float* __restrict__ dy, long long dbs,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, float* dgamma,
+                                                                   float* dbeta, int N, int C, int HW, int accum) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.x;
+  float sg = 0.0f, sb = 0.0f;
+  const long long total = (long long)N * HW;
+  for (long long i = threadIdx.x; i < total; i += 256) {
+    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+    const float g = dy[n * dbs + (long long)c * HW + p];
+    const float xh = (x[n * xbs + (long long)c * HW + p] - mean[i]) * rstd[i];
+    sg += g * xh;
+    sb += g;
+  }
+  sg = wave_sum(sg);
+  sb = wave_sum(sb);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    float b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (accum) { a += dgamma[c]; b += dbeta[c]; }
+    dgamma[c] = a;
+    dbeta[c] = b;
+  }
+}
+// PatchMerging gather (stf.py:224-228): dst[n][k*C + c][y][x] = src[n][c][2y + (k&1)][2x + (k>>1)]; inverse = its gradient
+__global__ void space_to_depth2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H,
+                                       int W, int inverse, int accum) {
+  const int H2 = H / 2, W2 = W / 2;
+  const long long total = (long long)N * 4 * C * H2 * W2;
+  GRID_STRIDE(i, total) {
+    const int x = (int)(i % W2);
+    long long q = i / W2;
+    const int y = (int)(q % H2); q /= H2;
+    const int kc = (int)(q % (4 * C));
+    const int n = (int)(q / (4 * C));
+    const int k = kc / C, c = kc - k * C;
+    const long long big = (((long long)n * C + c) * H + 2 * y + (k & 1)) * W + 2 * x + (k >> 1);
+    if (!inverse) dst[i] = src[big];
+    else {
+      float v = src[i];
+      if (accum) v += dst[big];
+      dst[big] = v;
+    }
+  }
+}
+// DropPath residual (stf.py:190-191): out[n] = shortcut[n] + scale[n] * branch[n]; backward d_branch = scale[n]*g
+__global__ void residual_scale_kernel(const float* __restrict__ shortcut, const float* __restrict__ branch,
+                                      const float* __restrict__ scale, float* __restrict__ out, long long per,
+                                      long long n) {
+  GRID_STRIDE(i, n) {
+    const float s = scale[i / per];
+    out[i] = (shortcut ? shortcut[i] : 0.0f) + s * branch[i];
+  }
+}
 __global__ void fill_kernel(float* p, long long n, float v) {
   GRID_STRIDE(i, n) p[i] = v;
 }
@@ -315,6 +426,45 @@ int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int 
   if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0) return ICM_ERR_ARG;
   hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for((long long)N * C * 4 * H * W)), dim3(256), 0, ST, src, dst,
                      N, C, H, W);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const float* beta, float* y, int64_t y_bs,
+                      float* mean, float* rstd, int N, int C, int HW, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for((long long)N * HW, 1)), dim3(256), 0, ST, x, (long long)x_bs,
+                     gamma, beta, y, (long long)y_bs, mean, rstd, N, C, HW, eps);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* gamma,
+                      const float* mean, const float* rstd, float* dx, int64_t dx_bs, float* dgamma, float* dbeta,
+                      int N, int C, int HW, int accum_dx, int accum_params, void* stream) {
+  if (!x || !dy || !gamma || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  if (dx) {
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid_for((long long)N * HW, 1)), dim3(256), 0, ST, x, (long long)x_bs,
+                       dy, (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx);
+    ICM_CHECK_LAUNCH();
+  }
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(C), dim3(256), 0, ST, x, (long long)x_bs, dy, (long long)dy_bs,
+                       mean, rstd, dgamma, dbeta, N, C, HW, accum_params);
+    ICM_CHECK_LAUNCH();
+  }
+  return ICM_OK;
+}
+int icm_space_to_depth2(const float* src, float* dst, int N, int C, int H, int W, int inverse, int accum, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for((long long)N * C * H * W)), dim3(256), 0, ST, src, dst, N, C,
+                     H, W, inverse, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_residual_scale(const float* shortcut, const float* branch, const float* scale, float* out, int N,
+                       int64_t per_sample, void* stream) {
+  if (!branch || !scale || !out || N <= 0 || per_sample <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(residual_scale_kernel, dim3(grid_for((long long)N * per_sample)), dim3(256), 0, ST, shortcut,
+                     branch, scale, out, (long long)per_sample, (long long)N * per_sample);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

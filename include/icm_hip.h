@@ -145,6 +145,21 @@ int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int 
 /* strided 4-D copy (chunk/cat plumbing): dst[n,c,p] (+)= src[n,c,p] */
 int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int N, int C, int HW, int accum, void* stream);
 
+/* ---- stf (Swin) pieces on NCHW tensors ------------------------------------------------------------------
+ * nn.LayerNorm(C) over the channel axis per pixel (compressai/models/stf.py:136,142,209,250,372): y = (x-mean)*rstd*gamma+beta;
+ * mean/rstd [N*HW] are saved for backward (may be NULL in inference) */
+int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const float* beta, float* y, int64_t y_bs,
+                      float* mean, float* rstd, int N, int C, int HW, float eps, void* stream);
+int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* gamma,
+                      const float* mean, const float* rstd, float* dx, int64_t dx_bs, float* dgamma, float* dbeta,
+                      int N, int C, int HW, int accum_dx, int accum_params, void* stream);
+/* PatchMerging's 2x2 gather (stf.py:224-228): dst[n][k*C+c][y][x] = src[n][c][2y+(k&1)][2x+(k>>1)]; inverse=1 scatters
+ * a [N,4C,H/2,W/2] gradient back into [N,C,H,W] */
+int icm_space_to_depth2(const float* src, float* dst, int N, int C, int H, int W, int inverse, int accum, void* stream);
+/* DropPath residual (stf.py:190-191): out[n] = shortcut[n] + scale[n]*branch[n] (shortcut may be NULL) */
+int icm_residual_scale(const float* shortcut, const float* branch, const float* scale, float* out, int N,
+                       int64_t per_sample, void* stream);
+
 /* ---- window attention core (layers/win_attention.py:84-115,153-207) --------------------------
  * qkv: [N][3*C][H][W] (output of the qkv Linear run as a 1x1 conv on NCHW; channel = which*C + head*hd + d)
  * out: [N][C][H][W] (channel = head*hd + d), input of the proj Linear.  Cyclic shift, window partition,
