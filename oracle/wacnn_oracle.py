@@ -281,30 +281,27 @@ def g_s(y_hat, sd):
     return deconv(x, sd, "g_s.8")
 
 
-def wacnn_forward(sd: Dict[str, Tensor], x: Tensor, noise: Optional[Dict[str, Tensor]] = None,
-                  keep: bool = False) -> Dict:
-    """WACNN.forward. compressai/models/cnn.py:141-189.
-
-    noise: None -> eval-mode quantisation.  Else {"z": [B,192,h,w], "y": [B,320,H,W]} uniform
-    (-0.5,0.5) samples injected where the reference draws them in train mode
-    (entropy_models.py:131-135) -- only the *likelihood* inputs are noised; z_hat / y_hat use
-    ste_round in both modes (cnn.py:150-152,173)."""
-    y = g_a(x, sd)
+def hyper_slices(y: Tensor, sd: Dict[str, Tensor], noise: Optional[Dict[str, Tensor]], num_slices: int,
+                 max_support: int):
+    """Hyperprior + channel-conditional slice loop shared by the cnn and stf models
+    (cnn.py:144-183 == stf.py:596-637).  Returns (y_hat, y_lik, z_lik, dbg)."""
     z = h_a(y, sd)
     _, z_lik = eb_likelihood(z, sd, "entropy_bottleneck", None if noise is None else noise["z"])
     med = sd["entropy_bottleneck.quantiles"][:, :, 1:2].reshape(1, -1, 1, 1)
     z_hat = ste_round(z - med) + med
     lat_scales = h_s(z_hat, sd, "h_scale_s")
     lat_means = h_s(z_hat, sd, "h_mean_s")
-    y_slices = y.chunk(NUM_SLICES, 1)
-    n_slices = None if noise is None else noise["y"].chunk(NUM_SLICES, 1)
+    y_slices = y.chunk(num_slices, 1)
+    n_slices = None if noise is None else noise["y"].chunk(num_slices, 1)
     y_hat_slices, liks, mus, scales = [], [], [], []
     for i, ys in enumerate(y_slices):
-        sup = y_hat_slices[:MAX_SUPPORT]
+        sup = y_hat_slices[:max_support]
         mean_sup = torch.cat([lat_means] + sup, 1)
         mu = _seq_convs(mean_sup, sd, f"cc_mean_transforms.{i}", (0, 2, 4, 6, 8))
+        mu = mu[:, :, :y.shape[2], :y.shape[3]]
         scale_sup = torch.cat([lat_scales] + sup, 1)
         sc = _seq_convs(scale_sup, sd, f"cc_scale_transforms.{i}", (0, 2, 4, 6, 8))
+        sc = sc[:, :, :y.shape[2], :y.shape[3]]
         _, lik = gaussian_likelihood(ys, sc, mu, None if noise is None else n_slices[i])
         liks.append(lik)
         yh = ste_round(ys - mu) + mu
@@ -315,11 +312,25 @@ def wacnn_forward(sd: Dict[str, Tensor], x: Tensor, noise: Optional[Dict[str, Te
         scales.append(sc)
     y_hat = torch.cat(y_hat_slices, 1)
     y_lik = torch.cat(liks, 1)
+    dbg = {"y": y, "z": z, "z_hat": z_hat, "y_hat": y_hat, "mu": torch.cat(mus, 1),
+           "scale": torch.cat(scales, 1), "lat_means": lat_means, "lat_scales": lat_scales}
+    return y_hat, y_lik, z_lik, dbg
+
+
+def wacnn_forward(sd: Dict[str, Tensor], x: Tensor, noise: Optional[Dict[str, Tensor]] = None,
+                  keep: bool = False) -> Dict:
+    """WACNN.forward. compressai/models/cnn.py:141-189.
+
+    noise: None -> eval-mode quantisation.  Else {"z": [B,192,h,w], "y": [B,320,H,W]} uniform
+    (-0.5,0.5) samples injected where the reference draws them in train mode
+    (entropy_models.py:131-135) -- only the *likelihood* inputs are noised; z_hat / y_hat use
+    ste_round in both modes (cnn.py:150-152,173)."""
+    y = g_a(x, sd)
+    y_hat, y_lik, z_lik, dbg = hyper_slices(y, sd, noise, NUM_SLICES, MAX_SUPPORT)
     x_hat = g_s(y_hat, sd)
     out = {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
     if keep:
-        out["_dbg"] = {"y": y, "z": z, "z_hat": z_hat, "y_hat": y_hat, "mu": torch.cat(mus, 1),
-                       "scale": torch.cat(scales, 1), "lat_means": lat_means, "lat_scales": lat_scales}
+        out["_dbg"] = dbg
     return out
 
 

@@ -157,8 +157,12 @@ for _i in range(10):
 
 
 def make_wacnn_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return _make(wacnn_spec(), GAINS, salt)
+
+
+def _make(spec, gains, salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for key, shp in wacnn_spec().items():
+    for key, shp in spec.items():
         if isinstance(shp[0], str):
             dt = torch.int64 if shp[0] == "int64" else torch.int32
             if key.endswith("relative_position_index"):
@@ -204,6 +208,8 @@ def make_wacnn_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
             t = _u(key, shp, -0.5, 0.5, salt)
         elif leaf.startswith("_factor"):
             t = _u(key, shp, -0.5, 0.5, salt)
+        elif leaf == "weight" and len(shp) == 1:
+            t = 1.0 + _u(key, shp, -0.2, 0.2, salt)       # LayerNorm weight
         elif leaf == "weight":
             if len(shp) == 4:
                 # Conv2d [co,ci,k,k] and ConvTranspose2d [ci,co,k,k]: torch uses size(1)*k*k as fan_in
@@ -212,7 +218,7 @@ def make_wacnn_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
                 fan_in = shp[1]
             b = 1.0 / math.sqrt(fan_in)
             t = _u(key, shp, -b, b, salt)
-            t = t * GAINS.get(key, 1.0)
+            t = t * gains.get(key, 1.0)
         elif leaf == "bias":
             if key.startswith("cc_scale_transforms") and key.endswith(".8.bias"):
                 t = _u(key, shp, 0.0, 1.6, salt)
@@ -222,3 +228,80 @@ def make_wacnn_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
             raise KeyError(key)
         sd[key] = t.to(torch.float32).reshape(shp).contiguous()
     return sd
+
+
+# ----------------------------------------------------------------------------- stf (SymmetricalTransFormer)
+def _swin_spec(s, p, dim, heads, ws=4):
+    s[p + ".norm1.weight"] = (dim,)
+    s[p + ".norm1.bias"] = (dim,)
+    s[p + ".attn.relative_position_bias_table"] = ((2 * ws - 1) ** 2, heads)
+    s[p + ".attn.relative_position_index"] = ("int64", (ws * ws, ws * ws))
+    s[p + ".attn.qkv.weight"] = (3 * dim, dim)
+    s[p + ".attn.qkv.bias"] = (3 * dim,)
+    s[p + ".attn.proj.weight"] = (dim, dim)
+    s[p + ".attn.proj.bias"] = (dim,)
+    s[p + ".norm2.weight"] = (dim,)
+    s[p + ".norm2.bias"] = (dim,)
+    s[p + ".mlp.fc1.weight"] = (4 * dim, dim)
+    s[p + ".mlp.fc1.bias"] = (4 * dim,)
+    s[p + ".mlp.fc2.weight"] = (dim, 4 * dim)
+    s[p + ".mlp.fc2.bias"] = (dim,)
+
+
+def stf_spec(embed: int = 48) -> "OrderedDict[str, tuple]":
+    """Ordered key -> shape of SymmetricalTransFormer.state_dict() (compressai/models/stf.py:318-500)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    depths, heads = (2, 2, 6, 2), (3, 6, 12, 24)
+    s["patch_embed.proj.weight"] = (embed, 3, 2, 2)
+    s["patch_embed.proj.bias"] = (embed,)
+    s["patch_embed.norm.weight"] = (embed,)
+    s["patch_embed.norm.bias"] = (embed,)
+    for i in range(4):
+        dim = embed * 2 ** i
+        for j in range(depths[i]):
+            _swin_spec(s, f"layers.{i}.blocks.{j}", dim, heads[i])
+        if i < 3:   # PatchMerging (stf.py:196-201)
+            s[f"layers.{i}.downsample.reduction.weight"] = (2 * dim, 4 * dim)
+            s[f"layers.{i}.downsample.norm.weight"] = (4 * dim,)
+            s[f"layers.{i}.downsample.norm.bias"] = (4 * dim,)
+    for i in range(4):
+        dim = embed * 2 ** (3 - i)
+        for j in range(depths[3 - i]):
+            _swin_spec(s, f"syn_layers.{i}.blocks.{j}", dim, heads[3 - i])
+        if i < 3:   # PatchSplit (stf.py:242-247)
+            s[f"syn_layers.{i}.downsample.reduction.weight"] = (2 * dim, dim)
+            s[f"syn_layers.{i}.downsample.norm.weight"] = (dim,)
+            s[f"syn_layers.{i}.downsample.norm.bias"] = (dim,)
+    _conv_spec(s, "end_conv.0", embed * 4, embed, 5)
+    _conv_spec(s, "end_conv.2", 3, embed, 3)
+    for i, (ci, co) in zip((0, 2, 4, 6, 8), ((384, 384), (384, 336), (336, 288), (288, 240), (240, 192))):
+        _conv_spec(s, f"h_a.{i}", co, ci, 3)
+    for h in ("h_mean_s", "h_scale_s"):
+        _conv_spec(s, f"{h}.0", 240, 192, 3)
+        _conv_spec(s, f"{h}.2.0", 288 * 4, 240, 3)
+        _conv_spec(s, f"{h}.4", 336, 288, 3)
+        _conv_spec(s, f"{h}.6.0", 384 * 4, 336, 3)
+        _conv_spec(s, f"{h}.8", 384, 384, 3)
+    chain = (224, 176, 128, 64, 32)
+    for fam, extra in (("cc_mean_transforms", 0), ("cc_scale_transforms", 0), ("lrp_transforms", 1)):
+        for i in range(12):
+            ci = 384 + 32 * min(i + extra, 6 + extra)
+            for j, co in zip((0, 2, 4, 6, 8), chain):
+                _conv_spec(s, f"{fam}.{i}.{j}", co, ci, 3)
+                ci = co
+    tail = wacnn_spec()
+    for k, v in tail.items():
+        if k.startswith(("entropy_bottleneck.", "gaussian_conditional.")):
+            s[k] = v
+    return s
+
+
+STF_GAINS = {"layers.3.blocks.1.mlp.fc2.weight": 6.0, "h_a.8.weight": 80.0}
+for _i in range(12):
+    STF_GAINS[f"cc_scale_transforms.{_i}.8.weight"] = 12.0
+    STF_GAINS[f"cc_mean_transforms.{_i}.8.weight"] = 8.0
+    STF_GAINS[f"lrp_transforms.{_i}.8.weight"] = 8.0
+
+
+def make_stf_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return _make(stf_spec(), STF_GAINS, salt)

@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 from _ref_loader import load_reference  # noqa: E402
 from oracle import weights as W  # noqa: E402
 from oracle import wacnn_oracle as O  # noqa: E402
+from oracle import stf_oracle as S  # noqa: E402
 
 torch.set_num_threads(8)
 cnn_mod, stf_mod = load_reference()
@@ -80,6 +81,8 @@ def fill_module(mod, prefix):
             new[k] = v + U(key, v.shape, -0.3, 0.3)
         elif leaf.startswith("_bias") or leaf.startswith("_factor"):
             new[k] = U(key, v.shape, -0.5, 0.5)
+        elif leaf == "weight" and v.dim() == 1:
+            new[k] = 1.0 + U(key, v.shape, -0.2, 0.2)
         elif leaf == "weight":
             fan_in = int(np.prod(v.shape[1:]))
             b = 1.0 / math.sqrt(fan_in)
@@ -385,10 +388,190 @@ def gen_wacnn():
     save("wacnn_e2e", lmbda=np.float32(lmbda), **ev, **tr)
 
 
+class _InjectedDropPath(torch.nn.Module):
+    """stands in for timm's DropPath while capturing fixtures: the i-th call multiplies by scales[i] (per sample)"""
+
+    def __init__(self, scales):
+        super().__init__()
+        self.scales, self.i = scales, 0
+
+    def forward(self, x):
+        s = self.scales[self.i % self.scales.shape[0]]
+        self.i += 1
+        return x * s.view(-1, *([1] * (x.ndim - 1)))
+
+
+def gen_stf_ops():
+    print("stf ops")
+    # SwinTransformerBlock dim 48 / 3 heads / ws 4 (hd 16), shifted and not, with DropPath scales; 12x8 map
+    for tag, shift in (("swin_d48_shift2", 2), ("swin_d48_noshift", 0)):
+        blk = stf_mod.SwinTransformerBlock(dim=48, num_heads=3, window_size=4, shift_size=shift, drop_path=0.1)
+        sd = fill_module(blk, tag)
+        B, H, Wd = 2, 12, 8
+        x = U(tag + ".x", (B, H * Wd, 48), -1.5, 1.5).requires_grad_(True)
+        g = U(tag + ".g", (B, H * Wd, 48), -1.0, 1.0)
+        dp = torch.tensor([[1.0 / 0.9, 0.0], [1.0 / 0.9, 1.0 / 0.9]])   # [2 calls, B]
+        blk.drop_path = _InjectedDropPath(dp)
+        blk.H, blk.W = H, Wd
+        mask = O.shift_mask(H, Wd, 4, shift) if shift else None
+        y = blk(x, mask)
+        pn = [n for n, _ in blk.named_parameters()]
+        gs = torch.autograd.grad(y, [x] + [p_ for _, p_ in blk.named_parameters()], g)
+        s = leafify(sd)
+        y2 = S.swin_block(x, H, Wd, s, tag, 3, 4, shift, dp)
+        gs2 = torch.autograd.grad(y2, [x] + [s[tag + "." + n] for n in pn], g)
+        check(y2, y, tag + ".y", 1e-6)
+        for a, b, k in zip(gs2, gs, ["x"] + pn):
+            check(a, b, tag + ".grad." + k, 5e-6)
+        save(tag, x=x, g=g, dp=dp, y=y, gx=gs[0], **{"g_" + n: a for n, a in zip(pn, gs[1:])},
+             **{k[len(tag) + 1:]: v for k, v in sd.items() if v.dtype.is_floating_point})
+    # PatchMerging dim 48 (-> 96) and PatchSplit dim 96 (-> 48), 8x12 map
+    for tag, cls, dim in (("patch_merge_d48", stf_mod.PatchMerging, 48), ("patch_split_d96", stf_mod.PatchSplit, 96)):
+        mod = cls(dim=dim)
+        sd = fill_module(mod, tag)
+        B, H, Wd = 2, 8, 12
+        x = U(tag + ".x", (B, H * Wd, dim), -1.5, 1.5).requires_grad_(True)
+        y = mod(x, H, Wd)
+        g = U(tag + ".g", tuple(y.shape), -1.0, 1.0)
+        pn = [n for n, _ in mod.named_parameters()]
+        gs = torch.autograd.grad(y, [x] + [p_ for _, p_ in mod.named_parameters()], g)
+        s = leafify(sd)
+        f = S.patch_merging if cls is stf_mod.PatchMerging else S.patch_split
+        y2 = f(x, H, Wd, s, tag)
+        gs2 = torch.autograd.grad(y2, [x] + [s[tag + "." + n] for n in pn], g)
+        check(y2, y, tag + ".y", 1e-6)
+        for a, b, k in zip(gs2, gs, ["x"] + pn):
+            check(a, b, tag + ".grad." + k, 5e-6)
+        save(tag, x=x, g=g, y=y, gx=gs[0], **{"g_" + n: a for n, a in zip(pn, gs[1:])},
+             **{k[len(tag) + 1:]: v for k, v in sd.items() if v.dtype.is_floating_point})
+
+
+def gen_stf():
+    print("stf end-to-end")
+    sd = W.make_stf_state_dict()
+    model = stf_mod.SymmetricalTransFormer()
+    rsd = model.state_dict()
+    assert list(rsd.keys()) == list(sd.keys()), "stf state-dict key order/list differs from reference"
+    for k, v in rsd.items():
+        assert tuple(v.shape) == tuple(sd[k].shape) and v.dtype == sd[k].dtype, k
+        if k.rsplit(".", 1)[-1] in ("pedestal", "bound", "target", "scale_bound", "relative_position_index"):
+            assert torch.equal(v, sd[k]), k
+    with open(os.path.join(HERE, "stf_keys.json"), "w") as f:
+        json.dump([[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in rsd.items()], f)
+    # the reference's own load_state_dict override (stf.py:654-663) only resizes CDF buffers, then defers to nn.Module
+    torch.nn.Module.load_state_dict(model, sd)
+    rates = S.drop_path_rates()
+    for name, mod in model.named_modules():
+        if isinstance(mod, stf_mod.SwinTransformerBlock):
+            r = rates[name]
+            have = 0.0 if isinstance(mod.drop_path, torch.nn.Identity) else mod.drop_path.p
+            assert abs(have - r) < 1e-7, (name, have, r)
+    x = U("stf.x", (1, 3, 256, 256), 0.0, 1.0)
+    lmbda = 0.0067
+    model.eval()
+    with torch.no_grad():
+        o_ref = model(x)
+        o = S.stf_forward(sd, x, keep=True)
+    for k in ("y", "z"):
+        check(o["likelihoods"][k], o_ref["likelihoods"][k], "stf.eval.lik." + k)
+    check(o["x_hat"], o_ref["x_hat"], "stf.eval.x_hat")
+    L = O.rd_loss(x, o_ref, lmbda)
+    d = o["_dbg"]
+    r = d["y"] - d["mu"]
+    margin_y = (r - torch.floor(r) - 0.5).abs()
+    npix = 256 * 256
+    ev = dict(
+        bpp_y=(torch.log(o_ref["likelihoods"]["y"]).sum() / (-math.log(2) * npix)),
+        bpp_z=(torch.log(o_ref["likelihoods"]["z"]).sum() / (-math.log(2) * npix)),
+        bpp=L["bpp_loss"], mse=L["mse_loss"], loss=L["loss"],
+        x_hat_crop=o_ref["x_hat"][0, :, 96:128, 160:192], x_hat_sum=o_ref["x_hat"].double().sum(),
+        lik_y=o_ref["likelihoods"]["y"], lik_z=o_ref["likelihoods"]["z"],
+        y=d["y"], z=d["z"], y_hat=d["y_hat"], mu=d["mu"], scale=d["scale"],
+        margin_y_min=margin_y.min(), margin_y_lt_1e4=(margin_y < 1e-4).sum(), margin_y_lt_1e3=(margin_y < 1e-3).sum(),
+    )
+    print("  eval:", {k: float(v) for k, v in ev.items() if v.numel() == 1})
+    # --- train mode: injected quantisation noise and DropPath scales, B=2 on a 128x128 crop pair + backward
+    B = 2
+    xt = U("stf.xt", (B, 3, 128, 128), 0.0, 1.0)
+    nz = U("stf.noise_z", (B, 192, 2, 2), -0.5, 0.5)
+    ny = U("stf.noise_y", (B, 384, 8, 8), -0.5, 0.5)
+    drops = {}
+    for name, rate in rates.items():
+        if rate > 0:
+            keep = 1.0 - rate
+            bern = (U("stf.dp." + name, (2, B), 0.0, 1.0) < keep).float()
+            drops[name] = bern / keep
+    assert any((v == 0).any() for v in drops.values()), "fixture should drop at least one branch"
+    model.train()
+    for name, mod in model.named_modules():
+        if isinstance(mod, stf_mod.SwinTransformerBlock) and name in drops:
+            mod.drop_path = _InjectedDropPath(drops[name])
+    orig = ref_em.EntropyModel.quantize
+    state = {"i": 0}
+
+    def q(self, inputs, m, means=None, _o=orig):
+        if m != "noise":
+            return _o(self, inputs, m, means)
+        if isinstance(self, ref_em.EntropyBottleneck):
+            return inputs + nz.transpose(0, 1).reshape(192, 1, -1)
+        i = state["i"]
+        state["i"] += 1
+        return inputs + ny[:, 32 * i:32 * (i + 1)]
+    ref_em.EntropyModel.quantize = q
+    model.zero_grad()
+    o_ref = model(xt)
+    ref_em.EntropyModel.quantize = orig
+    Lr = O.rd_loss(xt, o_ref, lmbda)
+    Lr["loss"].backward()
+    aux = model.aux_loss()
+    s = leafify(sd)
+    o = S.stf_forward(s, xt, {"z": nz, "y": ny}, drops)
+    Lo = O.rd_loss(xt, o, lmbda)
+    Lo["loss"].backward()
+    check(o["x_hat"], o_ref["x_hat"], "stf.train.x_hat", 1e-6)
+    check(Lo["loss"], Lr["loss"], "stf.train.loss", 1e-6)
+    worst = 0.0
+    gnorms, names = [], []
+    for n, p in model.named_parameters():
+        go = s[n].grad
+        gr = p.grad if p.grad is not None else torch.zeros_like(p)
+        go = go if go is not None else torch.zeros_like(p)
+        dd = (go - gr).abs().max().item() / max(gr.abs().max().item(), 1e-20)
+        worst = max(worst, dd)
+        gnorms.append(gr.double().norm().item())
+        names.append(n)
+    assert worst <= 1e-5, f"stf oracle grads differ from reference: {worst}"
+    print(f"  train: loss {Lr['loss'].item():.6f} bpp {Lr['bpp_loss'].item():.6f} mse {Lr['mse_loss'].item():.6f} "
+          f"aux {aux.item():.4f} worst rel grad diff oracle-vs-ref {worst:.2e}")
+    P = dict(model.named_parameters())
+    pick = ["patch_embed.proj.weight", "patch_embed.norm.bias", "layers.0.blocks.1.attn.relative_position_bias_table",
+            "layers.0.blocks.0.norm1.weight", "layers.2.blocks.3.mlp.fc1.bias", "layers.1.downsample.reduction.weight",
+            "layers.1.downsample.norm.weight", "syn_layers.0.downsample.reduction.weight",
+            "syn_layers.3.blocks.1.attn.qkv.bias", "syn_layers.1.blocks.5.norm2.bias", "end_conv.0.bias",
+            "end_conv.2.weight", "h_a.8.bias", "lrp_transforms.11.8.bias", "cc_scale_transforms.7.8.bias",
+            "entropy_bottleneck._matrix0"]
+    tr = dict(
+        t_bpp=Lr["bpp_loss"], t_mse=Lr["mse_loss"], t_loss=Lr["loss"], t_aux=aux,
+        t_x_hat_crop=o_ref["x_hat"][:, :, 32:64, 64:96], t_lik_z=o_ref["likelihoods"]["z"],
+        t_lik_y=o_ref["likelihoods"]["y"], t_grad_norms=np.array(gnorms), t_grad_names=np.array(names),
+        t_total_grad_norm=np.sqrt(np.sum(np.square(gnorms))),
+        t_drop_names=np.array(list(drops.keys())), t_drops=torch.stack(list(drops.values())),
+        **{"t_g_" + k: P[k].grad for k in pick},
+    )
+    save("stf_e2e", lmbda=np.float32(lmbda), **ev, **tr)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:     # python make_golden.py gen_stf gen_stf_ops ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        print("done")
+        sys.exit(0)
     gen_ops()
     gen_gdn()
     gen_attention()
     gen_entropy()
     gen_wacnn()
+    gen_stf_ops()
+    gen_stf()
     print("done")
