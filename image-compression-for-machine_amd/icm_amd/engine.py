@@ -473,15 +473,12 @@ def residual_unit(tape, xv: VT, P, p) -> VT:
     return VT(u3, ACT_GELU)
 
 
-def window_attention(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
-    """WinBasedAttention.forward (layers/win_attention.py:153-207): x + proj(attn(qkv(x)))."""
-    N, Cc, H, W = x.shape
-    if not (0 <= shift < ws):
-        raise AssertionError("shift_size must in 0-window_size")
-    table = P[p + ".attn.relative_position_bias_table"]
-    qkv = conv2d(tape, VT(x), P[p + ".attn.qkv.weight"], P[p + ".attn.qkv.bias"])
-    o = new(x)
-    check(L.lib().icm_winattn_fwd(ptr(qkv), ptr(table), ptr(o), N, Cc, H, W, heads, ws, shift, tape.st), "winattn_fwd")
+def window_msa_core(tape, qkv, table, C_, heads, ws, shift) -> torch.Tensor:
+    """softmax(q k^T / sqrt(hd) + bias (+ shift mask)) v per window and head, straight on the NCHW qkv tensor
+    (win_attention.py:84-115 / stf.py:95-121; roll + window_partition + mask are address arithmetic)."""
+    N, _, H, W = qkv.shape
+    o = torch.empty((N, C_, H, W), dtype=torch.float32, device=qkv.device)
+    check(L.lib().icm_winattn_fwd(ptr(qkv), ptr(table), ptr(o), N, C_, H, W, heads, ws, shift, tape.st), "winattn_fwd")
     if tape.need_grad:
         def bwd():
             do = tape.grad_of(o)
@@ -492,10 +489,125 @@ def window_attention(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
             gt, acct = tape.grad_for_write(table)
             if not acct:
                 check(L.lib().icm_fill(ptr(gt), gt.numel(), 0.0, tape.st), "fill")
-            check(L.lib().icm_winattn_bwd(ptr(qkv), ptr(table), ptr(do), ptr(dqkv), ptr(gt), N, Cc, H, W, heads, ws,
+            check(L.lib().icm_winattn_bwd(ptr(qkv), ptr(table), ptr(do), ptr(dqkv), ptr(gt), N, C_, H, W, heads, ws,
                                           shift, tape.st), "winattn_bwd")
         tape.bw.append(bwd)
+    return o
+
+
+def window_attention(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
+    """WinBasedAttention.forward (layers/win_attention.py:153-207): x + proj(attn(qkv(x)))."""
+    N, Cc, H, W = x.shape
+    if not (0 <= shift < ws):
+        raise AssertionError("shift_size must in 0-window_size")
+    table = P[p + ".attn.relative_position_bias_table"]
+    qkv = conv2d(tape, VT(x), P[p + ".attn.qkv.weight"], P[p + ".attn.qkv.bias"])
+    o = window_msa_core(tape, qkv, table, Cc, heads, ws, shift)
     return conv2d(tape, VT(o), P[p + ".attn.proj.weight"], P[p + ".attn.proj.bias"], res=VT(x))
+
+
+# ------------------------------------------------------------------------------------------------ stf (Swin) pieces
+LN_EPS = 1e-5
+
+
+def layernorm(tape, x, gamma, beta) -> torch.Tensor:
+    """nn.LayerNorm(C) over the channel axis of an NCHW tensor (= per token; stf.py:136,142,200,246,350)."""
+    N, Cc, H, W = x.shape
+    if gamma.shape != (Cc,) or beta.shape != (Cc,):
+        raise ValueError("LayerNorm: channel mismatch")
+    HW = H * W
+    y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    need = tape.need_grad
+    mean = torch.empty(N * HW, dtype=torch.float32, device=x.device) if need else None
+    rstd = torch.empty(N * HW, dtype=torch.float32, device=x.device) if need else None
+    check(L.lib().icm_layernorm_fwd(ptr(x), bs(x), ptr(gamma), ptr(beta), ptr(y), bs(y), ptr(mean), ptr(rstd), N, Cc, HW,
+                                    LN_EPS, tape.st), "layernorm_fwd")
+    if need:
+        def bwd():
+            dy = tape.grad_of(y)
+            if dy is None:
+                return
+            gg = gb_ = dx = None
+            ap = ax = 0
+            if tape.wants(gamma):
+                gg, ap = tape.grad_for_write(gamma)
+                gb_, ap2 = tape.grad_for_write(beta)
+                assert ap == ap2
+            if tape.wants(x):
+                dx, ax = tape.grad_for_write(x)
+            check(L.lib().icm_layernorm_bwd(ptr(x), bs(x), ptr(dy), bs(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                            bs(dx), ptr(gg), ptr(gb_), N, Cc, HW, ax, ap, tape.st), "layernorm_bwd")
+        tape.bw.append(bwd)
+    return y
+
+
+def residual_scale(tape, shortcut, branch, scale) -> torch.Tensor:
+    """shortcut + DropPath(branch) with per-sample scales (0 or 1/keep_prob; stf.py:190-191)."""
+    N = branch.shape[0]
+    per = branch[0].numel()
+    assert shortcut.is_contiguous() and branch.is_contiguous()
+    out = torch.empty_like(branch)
+    check(L.lib().icm_residual_scale(ptr(shortcut), ptr(branch), ptr(scale), ptr(out), N, per, tape.st), "residual_scale")
+    if tape.need_grad:
+        def bwd():
+            g = tape.grad_of(out)
+            if g is None:
+                return
+            accumulate(tape, shortcut, g)
+            db, acc = tape.grad_for_write(branch)
+            assert acc == 0 and db.is_contiguous()
+            check(L.lib().icm_residual_scale(0, ptr(g), ptr(scale), ptr(db), N, per, tape.st), "residual_scale_bwd")
+        tape.bw.append(bwd)
+    return out
+
+
+def swin_block(tape, x, P, p, heads, ws, shift, dp=None) -> torch.Tensor:
+    """SwinTransformerBlock.forward (stf.py:149-193) on an NCHW map: LN -> (S)W-MSA -> +shortcut -> LN -> MLP -> +.
+    dp: None or a [2, N] device tensor of DropPath scales (attention branch, MLP branch)."""
+    N, Cc, H, W = x.shape
+    if H % ws or W % ws:
+        raise ValueError("swin_block: feature map must be a multiple of the window size (inputs are multiples of 64)")
+    n1 = layernorm(tape, x, P[p + ".norm1.weight"], P[p + ".norm1.bias"])
+    qkv = conv2d(tape, VT(n1), P[p + ".attn.qkv.weight"], P[p + ".attn.qkv.bias"])
+    o = window_msa_core(tape, qkv, P[p + ".attn.relative_position_bias_table"], Cc, heads, ws, shift)
+    if dp is None:
+        x1 = conv2d(tape, VT(o), P[p + ".attn.proj.weight"], P[p + ".attn.proj.bias"], res=VT(x))
+    else:
+        a = conv2d(tape, VT(o), P[p + ".attn.proj.weight"], P[p + ".attn.proj.bias"])
+        x1 = residual_scale(tape, x, a, dp[0])
+    n2 = layernorm(tape, x1, P[p + ".norm2.weight"], P[p + ".norm2.bias"])
+    hdn = conv2d(tape, VT(n2), P[p + ".mlp.fc1.weight"], P[p + ".mlp.fc1.bias"])
+    if dp is None:
+        return conv2d(tape, VT(hdn, ACT_GELU), P[p + ".mlp.fc2.weight"], P[p + ".mlp.fc2.bias"], res=VT(x1))
+    m = conv2d(tape, VT(hdn, ACT_GELU), P[p + ".mlp.fc2.weight"], P[p + ".mlp.fc2.bias"])
+    return residual_scale(tape, x1, m, dp[1])
+
+
+def patch_merging(tape, x, P, p) -> torch.Tensor:
+    """PatchMerging.forward (stf.py:203-233): 2x2 gather -> LayerNorm(4C) -> Linear(4C, 2C, bias=False)."""
+    N, Cc, H, W = x.shape
+    if H % 2 or W % 2:
+        raise ValueError("patch_merging: odd feature maps need padding (inputs are multiples of 64)")
+    assert x.is_contiguous()
+    g4 = torch.empty((N, 4 * Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    check(L.lib().icm_space_to_depth2(ptr(x), ptr(g4), N, Cc, H, W, 0, 0, tape.st), "space_to_depth2")
+    if tape.need_grad:
+        def bwd():
+            g = tape.grad_of(g4)
+            if g is None or not tape.wants(x):
+                return
+            dx, acc = tape.grad_for_write(x)
+            assert dx.is_contiguous() and g.is_contiguous()
+            check(L.lib().icm_space_to_depth2(ptr(g), ptr(dx), N, Cc, H, W, 1, acc, tape.st), "depth_to_space2")
+        tape.bw.append(bwd)
+    n = layernorm(tape, g4, P[p + ".norm.weight"], P[p + ".norm.bias"])
+    return conv2d(tape, VT(n), P[p + ".reduction.weight"], None)
+
+
+def patch_split(tape, x, P, p) -> torch.Tensor:
+    """PatchSplit.forward (stf.py:249-259): LayerNorm(C) -> Linear(C, 2C, bias=False) -> PixelShuffle(2) (fused store)."""
+    n = layernorm(tape, x, P[p + ".norm.weight"], P[p + ".norm.bias"])
+    return conv2d(tape, VT(n), P[p + ".reduction.weight"], None, pixel_shuffle=2)
 
 
 def attention_gate(tape, x, P, p, heads, ws, shift) -> torch.Tensor:

@@ -17,7 +17,8 @@ from . import engine as E
 from ._lib import ACT_GELU
 from .engine import VT
 from .entropy_models import EntropyBottleneck, GaussianConditional
-from .layers import (GDN, Win_noShift_Attention, conv, conv3x3, deconv, subpel_conv3x3, _named)
+from .layers import (GDN, Conv2d, Win_noShift_Attention, WindowAttention, conv, conv3x3, deconv, subpel_conv3x3,
+                     _named)
 
 SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
 
@@ -98,23 +99,14 @@ def _copy_op(tape, src, dst):
         tape.bw.append(bwd)
 
 
-def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise_z=None, noise_y=None,
-                  num_slices: int = 10, max_support: int = 5, keep: Optional[dict] = None,
-                  bucket_marks: Optional[dict] = None):
-    """WACNN.forward (models/cnn.py:141-189) on the HIP engine -> (x_hat, y_likelihoods, z_likelihoods)."""
-    dev = x.device
-    N = x.shape[0]
+def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, num_slices: int,
+                 max_support: int, keep: Optional[dict] = None, bucket_marks: Optional[dict] = None):
+    """Hyperprior + channel-conditional slice loop shared by the cnn and stf models
+    (cnn.py:144-183 == stf.py:596-637) -> (y_hat, y_likelihoods, z_likelihoods).  torch.cat / chunk become
+    channel-slice views of persistent support buffers."""
+    dev = y.device
+    N = y.shape[0]
     need = tape.need_grad
-    # ---- g_a (cnn.py:31-41)
-    t = E.conv2d(tape, VT(x), P["g_a.0.weight"], P["g_a.0.bias"], stride=2, pad=2)
-    t = E.gdn(tape, t, P["g_a.1.beta"], P["g_a.1.gamma"], False)
-    t = E.conv2d(tape, VT(t), P["g_a.2.weight"], P["g_a.2.bias"], stride=2, pad=2)
-    t = E.gdn(tape, t, P["g_a.3.beta"], P["g_a.3.gamma"], False)
-    t = E.attention_gate(tape, t, P, "g_a.4", 8, 8, 4)
-    t = E.conv2d(tape, VT(t), P["g_a.5.weight"], P["g_a.5.bias"], stride=2, pad=2)
-    t = E.gdn(tape, t, P["g_a.6.beta"], P["g_a.6.gamma"], False)
-    t = E.conv2d(tape, VT(t), P["g_a.7.weight"], P["g_a.7.bias"], stride=2, pad=2)
-    y = E.attention_gate(tape, t, P, "g_a.8", 8, 4, 2)
     M, h, w = y.shape[1], y.shape[2], y.shape[3]
     if M % num_slices != 0:
         raise ValueError("latent channels must divide into num_slices")
@@ -143,10 +135,10 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
             sl = slice(M + sc_ * j, M + sc_ * (j + 1))
             tape.bind_grad(MS[:, sl], dMS[:, sl], True)
             tape.bind_grad(SS[:, sl], dSS[:, sl], True)
+    if (h % 4) or (w % 4):
+        raise ValueError("hyper-synthesis output does not match the latent size (input must be a multiple of 64)")
     _h_s(tape, P, "h_scale_s", z_hat, SS[:, :M])
     _h_s(tape, P, "h_mean_s", z_hat, MS[:, :M])
-    if tuple(MS.shape[2:]) != (h, w):
-        raise ValueError("hyper-synthesis output does not match the latent size (input must be a multiple of 64)")
     Y_hat = E.new((N, M, h, w), dev)
     Y_lik = E.new((N, M, h, w), dev)
     if need:
@@ -181,7 +173,40 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
             mus.append(mu)
             scs.append(sc)
     if bucket_marks is not None:
-        bucket_marks[0] = len(tape.bw)   # => g_s gradients complete
+        bucket_marks[0] = len(tape.bw)   # => synthesis-transform gradients complete
+    if keep is not None:
+        keep.update(y=y, z=z, z_hat=z_hat, y_hat=Y_hat, mu=torch.cat(mus, 1), scale=torch.cat(scs, 1),
+                    lat_means=MS[:, :M], lat_scales=SS[:, :M])
+    return Y_hat, Y_lik, z_lik
+
+
+def _split_lik(tape, Y_lik, num_slices):
+    """runs FIRST in backward (registered last): hand the seeded d(y_likelihoods) to the per-slice consumers"""
+    sc_ = Y_lik.shape[1] // num_slices
+
+    def split():
+        g = tape.grad_of(Y_lik)
+        if g is not None:
+            for i in range(num_slices):
+                tape.bind_grad(Y_lik[:, i * sc_:(i + 1) * sc_], g[:, i * sc_:(i + 1) * sc_], True)
+    tape.bw.append(split)
+
+
+def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise_z=None, noise_y=None,
+                  num_slices: int = 10, max_support: int = 5, keep: Optional[dict] = None,
+                  bucket_marks: Optional[dict] = None):
+    """WACNN.forward (models/cnn.py:141-189) on the HIP engine -> (x_hat, y_likelihoods, z_likelihoods)."""
+    # ---- g_a (cnn.py:31-41)
+    t = E.conv2d(tape, VT(x), P["g_a.0.weight"], P["g_a.0.bias"], stride=2, pad=2)
+    t = E.gdn(tape, t, P["g_a.1.beta"], P["g_a.1.gamma"], False)
+    t = E.conv2d(tape, VT(t), P["g_a.2.weight"], P["g_a.2.bias"], stride=2, pad=2)
+    t = E.gdn(tape, t, P["g_a.3.beta"], P["g_a.3.gamma"], False)
+    t = E.attention_gate(tape, t, P, "g_a.4", 8, 8, 4)
+    t = E.conv2d(tape, VT(t), P["g_a.5.weight"], P["g_a.5.bias"], stride=2, pad=2)
+    t = E.gdn(tape, t, P["g_a.6.beta"], P["g_a.6.gamma"], False)
+    t = E.conv2d(tape, VT(t), P["g_a.7.weight"], P["g_a.7.bias"], stride=2, pad=2)
+    y = E.attention_gate(tape, t, P, "g_a.8", 8, 4, 2)
+    Y_hat, Y_lik, z_lik = hyper_slices(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks)
     # ---- g_s (cnn.py:42-52)
     t = E.attention_gate(tape, Y_hat, P, "g_s.0", 8, 4, 2)
     t = E.conv2d(tape, VT(t), P["g_s.1.weight"], P["g_s.1.bias"], stride=2, pad=2, transposed=True, output_padding=1)
@@ -193,18 +218,82 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
     t = E.gdn(tape, t, P["g_s.7.beta"], P["g_s.7.gamma"], True)
     x_hat = E.conv2d(tape, VT(t), P["g_s.8.weight"], P["g_s.8.bias"], stride=2, pad=2, transposed=True,
                      output_padding=1)
-    if need:
-        # runs FIRST in backward: hand the seeded d(y_likelihoods) to the per-slice consumers
-        def split():
-            g = tape.grad_of(Y_lik)
-            if g is not None:
-                for i in range(num_slices):
-                    tape.bind_grad(Y_lik[:, i * sc_:(i + 1) * sc_], g[:, i * sc_:(i + 1) * sc_], True)
-        tape.bw.append(split)
-    if keep is not None:
-        keep.update(y=y, z=z, z_hat=z_hat, y_hat=Y_hat, mu=torch.cat(mus, 1), scale=torch.cat(scs, 1),
-                    lat_means=MS[:, :M], lat_scales=SS[:, :M])
+    if tape.need_grad:
+        _split_lik(tape, Y_lik, num_slices)
     return x_hat, Y_lik, z_lik
+
+
+# ------------------------------------------------------------------------------------------------ stf
+STF_DEPTHS = (2, 2, 6, 2)
+STF_HEADS = (3, 6, 12, 24)
+
+
+def stf_drop_path_rates(drop_path_rate: float = 0.2, depths=STF_DEPTHS) -> Dict[str, float]:
+    """stf.py:357 + 361-398: linspace(0, rate, sum(depths)); the synthesis layers index the same list with the
+    reversed depths."""
+    dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+    out, o = {}, 0
+    for i, d in enumerate(depths):
+        for j in range(d):
+            out[f"layers.{i}.blocks.{j}"] = dpr[o + j]
+        o += d
+    o = 0
+    for i, d in enumerate(depths[::-1]):
+        for j in range(d):
+            out[f"syn_layers.{i}.blocks.{j}"] = dpr[o + j]
+        o += d
+    return out
+
+
+def _basic_layer(tape, P, p, t, depth, heads, ws, down, drops):
+    """BasicLayer.forward (stf.py:271-313): the SW-MSA mask is address arithmetic inside the attention kernel."""
+    for j in range(depth):
+        key = f"{p}.blocks.{j}"
+        t = E.swin_block(tape, t, P, key, heads, ws, 0 if j % 2 == 0 else ws // 2,
+                         None if drops is None else drops.get(key))
+    if down == "merge":
+        return E.patch_merging(tape, t, P, p + ".downsample")
+    if down == "split":
+        return E.patch_split(tape, t, P, p + ".downsample")
+    return t
+
+
+def stf_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise_z=None, noise_y=None,
+                drops: Optional[Dict[str, torch.Tensor]] = None, num_slices: int = 12, max_support: int = 6,
+                window: int = 4, keep: Optional[dict] = None, bucket_marks: Optional[dict] = None):
+    """SymmetricalTransFormer.forward (models/stf.py:582-645) on the HIP engine.  Tokens stay NCHW end to end:
+    [B, L, C] <-> [B, C, H, W] transposes of the reference vanish, Linear layers are 1x1 implicit GEMMs,
+    LayerNorm normalises the channel axis per pixel.  drops: {"<layer>.blocks.<j>": [2,B] DropPath scales}."""
+    if x.shape[2] % 2 or x.shape[3] % 2:
+        raise ValueError("stf_forward: odd image sizes need PatchEmbed padding (inputs are multiples of 64)")
+    # ---- patch_embed (stf.py:331-351): conv 2x2 s2 + LayerNorm
+    t = E.conv2d(tape, VT(x), P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=2, pad=0)
+    t = E.layernorm(tape, t, P["patch_embed.norm.weight"], P["patch_embed.norm.bias"])
+    for i in range(4):
+        t = _basic_layer(tape, P, f"layers.{i}", t, STF_DEPTHS[i], STF_HEADS[i], window, "merge" if i < 3 else None,
+                         drops)
+    y = t
+    Y_hat, Y_lik, z_lik = hyper_slices(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks)
+    t = Y_hat
+    for i in range(4):
+        t = _basic_layer(tape, P, f"syn_layers.{i}", t, STF_DEPTHS[3 - i], STF_HEADS[3 - i], window,
+                         "split" if i < 3 else None, drops)
+    # ---- end_conv (stf.py:401-404): conv5x5 -> PixelShuffle(2) (fused store) -> conv3x3
+    t = E.conv2d(tape, VT(t), P["end_conv.0.weight"], P["end_conv.0.bias"], pad=2, pixel_shuffle=2)
+    x_hat = E.conv2d(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
+    if tape.need_grad:
+        _split_lik(tape, Y_lik, num_slices)
+    return x_hat, Y_lik, z_lik
+
+
+def _train_noise(injected, x, cz, cy):
+    """U(-1/2,1/2) samples the entropy models add in train mode (entropy_models.py:131-135)"""
+    B, _, H, W = x.shape
+    dev = x.device
+    if injected is not None:
+        return (injected["z"].to(dev, torch.float32).contiguous(), injected["y"].to(dev, torch.float32).contiguous())
+    return (torch.rand((B, cz, H // 64, W // 64), dtype=torch.float32, device=dev) - 0.5,
+            torch.rand((B, cy, H // 16, W // 16), dtype=torch.float32, device=dev) - 0.5)
 
 
 class WACNN(CompressionModel):
@@ -265,13 +354,7 @@ class WACNN(CompressionModel):
         dev = x.device
         nz = ny = None
         if training:
-            B, _, H, W = x.shape
-            if self._noise is not None:
-                nz = self._noise["z"].to(dev, torch.float32).contiguous()
-                ny = self._noise["y"].to(dev, torch.float32).contiguous()
-            else:
-                nz = torch.rand((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev) - 0.5
-                ny = torch.rand((B, 320, H // 16, W // 16), dtype=torch.float32, device=dev) - 0.5
+            nz, ny = _train_noise(self._noise, x, 192, 320)
         ns, ms = self.num_slices, self.max_support_slices
 
         def runner(tape, xin, *ps):
@@ -283,5 +366,238 @@ class WACNN(CompressionModel):
     @classmethod
     def from_state_dict(cls, state_dict):
         net = cls(192, 320)
+        net.load_state_dict(state_dict)
+        return net
+
+
+# ------------------------------------------------------------------------------------------------ stf modules
+class Mlp(nn.Module):
+    """stf.py:24-40 (parameter holder; runs inside the model tape)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        if drop != 0.0:
+            raise NotImplementedError("icm Mlp: dropout is unused by the reference")
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+
+class SwinTransformerBlock(nn.Module):
+    """stf.py:124-193.  forward(x, mask_matrix=None) takes an NCHW map [B, C, H, W] (the reference's token layout
+    [B, H*W, C] is its transpose; the mask is derived inside the kernel, the argument is ignored)."""
+
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, inverse=False):
+        super().__init__()
+        self.dim, self.num_heads, self.window_size, self.shift_size = dim, num_heads, window_size, shift_size
+        self.mlp_ratio = mlp_ratio
+        assert 0 <= self.shift_size < self.window_size, "shift_size must in 0-window_size"
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention(dim, window_size=(window_size, window_size), num_heads=num_heads,
+                                    qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path_rate = float(drop_path)
+        self.drop_path = nn.Identity()   # stochastic depth is drawn by the model forward (per-sample scales)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.H = self.W = None
+
+    def forward(self, x, mask_matrix=None):
+        from .layers import run_module
+        h, ws, sh = self.num_heads, self.window_size, self.shift_size
+        dp = _draw_drop(self.drop_path_rate, x.shape[0], x.device) if self.training else None
+        return run_module(self, lambda tape, P, t: (E.swin_block(tape, t, {"b." + k: v for k, v in P.items()}, "b", h,
+                                                                 ws, sh, dp),), x.contiguous())[0]
+
+
+class PatchMerging(nn.Module):
+    """stf.py:196-233 on NCHW maps: [B, C, H, W] -> [B, 2C, H/2, W/2]."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x, H=None, W=None):
+        from .layers import run_module
+        return run_module(self, lambda tape, P, t: (E.patch_merging(tape, t, {"d." + k: v for k, v in P.items()}, "d"),),
+                          x.contiguous())[0]
+
+
+class PatchSplit(nn.Module):
+    """stf.py:236-259 on NCHW maps: [B, C, H, W] -> [B, C/2, 2H, 2W]."""
+
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(dim, dim * 2, bias=False)
+        self.norm = norm_layer(dim)
+        self.shuffle = nn.PixelShuffle(2)
+
+    def forward(self, x, H=None, W=None):
+        from .layers import run_module
+        return run_module(self, lambda tape, P, t: (E.patch_split(tape, t, {"d." + k: v for k, v in P.items()}, "d"),),
+                          x.contiguous())[0]
+
+
+class BasicLayer(nn.Module):
+    """stf.py:261-313 (parameter holder; stf_forward walks the blocks)."""
+
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0.,
+                 attn_drop=0., drop_path=0., norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False,
+                 inverse=False):
+        super().__init__()
+        self.window_size, self.shift_size, self.depth = window_size, window_size // 2, depth
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock(dim=dim, num_heads=num_heads, window_size=window_size,
+                                 shift_size=0 if (i % 2 == 0) else window_size // 2, mlp_ratio=mlp_ratio,
+                                 qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                 drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                 norm_layer=norm_layer, inverse=inverse) for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+
+class PatchEmbed(nn.Module):
+    """stf.py:316-351."""
+
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.in_chans, self.embed_dim = in_chans, embed_dim
+        self.proj = Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+
+def _draw_drop(rate: float, B: int, device):
+    """timm DropPath in train mode: per-sample Bernoulli(keep)/keep, one draw per residual branch -> [2, B]"""
+    if rate <= 0.0:
+        return None
+    keep = 1.0 - rate
+    return (torch.rand((2, B), device=device) < keep).to(torch.float32) / keep
+
+
+class SymmetricalTransFormer(CompressionModel):
+    """Swin-transformer codec (models/stf.py:318-645): same modules, names, defaults and state-dict as the
+    reference; ``forward`` runs as one tape of HIP kernels (``stf_forward``)."""
+
+    def __init__(self, pretrain_img_size=256, patch_size=2, in_chans=3, embed_dim=48, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=4, num_slices=12, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=nn.LayerNorm, patch_norm=True,
+                 frozen_stages=-1, use_checkpoint=False):
+        super().__init__()
+        if (patch_size, in_chans, embed_dim, list(depths), list(num_heads), mlp_ratio, patch_norm) != \
+                (2, 3, 48, [2, 2, 6, 2], [3, 6, 12, 24], 4., True) or drop_rate or attn_drop_rate or frozen_stages >= 0:
+            raise NotImplementedError("icm SymmetricalTransFormer: only the reference's default architecture")
+        self.pretrain_img_size = pretrain_img_size
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim
+        self.patch_norm = patch_norm
+        self.frozen_stages = frozen_stages
+        self.num_slices = num_slices
+        self.max_support_slices = num_slices // 2
+        self.window_size = window_size
+        self.drop_path_rate = drop_path_rate
+        self.patch_embed = PatchEmbed(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      norm_layer=norm_layer if patch_norm else None)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i), depth=depths[i], num_heads=num_heads[i], window_size=window_size,
+                mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if (i < self.num_layers - 1) else None, inverse=False))
+        depths, num_heads = depths[::-1], num_heads[::-1]
+        self.syn_layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.syn_layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** (3 - i)), depth=depths[i], num_heads=num_heads[i], window_size=window_size,
+                mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                downsample=PatchSplit if (i < self.num_layers - 1) else None, inverse=True))
+        self.end_conv = nn.Sequential(Conv2d(embed_dim, embed_dim * patch_size ** 2, kernel_size=5, stride=1, padding=2),
+                                      nn.PixelShuffle(patch_size),
+                                      Conv2d(embed_dim, 3, kernel_size=3, stride=1, padding=1))
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        self.g_a = None
+        self.g_s = None
+        self.h_a = nn.Sequential(conv3x3(384, 384), nn.GELU(), conv3x3(384, 336), nn.GELU(),
+                                 conv3x3(336, 288, stride=2), nn.GELU(), conv3x3(288, 240), nn.GELU(),
+                                 conv3x3(240, 192, stride=2))
+
+        def hs():
+            return nn.Sequential(conv3x3(192, 240), nn.GELU(), subpel_conv3x3(240, 288, 2), nn.GELU(),
+                                 conv3x3(288, 336), nn.GELU(), subpel_conv3x3(336, 384, 2), nn.GELU(),
+                                 conv3x3(384, 384))
+        self.h_mean_s = hs()
+        self.h_scale_s = hs()
+
+        def cc(extra):
+            return nn.ModuleList(nn.Sequential(
+                conv(384 + 32 * min(i + extra, 6 + extra), 224, stride=1, kernel_size=3), nn.GELU(),
+                conv(224, 176, stride=1, kernel_size=3), nn.GELU(),
+                conv(176, 128, stride=1, kernel_size=3), nn.GELU(),
+                conv(128, 64, stride=1, kernel_size=3), nn.GELU(),
+                conv(64, 32, stride=1, kernel_size=3)) for i in range(num_slices))
+        self.cc_mean_transforms = cc(0)
+        self.cc_scale_transforms = cc(0)
+        self.lrp_transforms = cc(1)
+        self.entropy_bottleneck = EntropyBottleneck(embed_dim * 4)
+        self.gaussian_conditional = GaussianConditional(None)
+        self._noise = None
+        self._drops = None
+
+    def inject_noise(self, noise: Optional[dict], drops: Optional[dict] = None):
+        """testing hook: {"z","y"} U(-1/2,1/2) samples and {"<layer>.blocks.<j>": [2,B]} DropPath scales (train mode)"""
+        self._noise, self._drops = noise, drops
+
+    def init_weights(self):
+        """stf.py:567-579"""
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+    def draw_drops(self, B: int, device) -> Dict[str, torch.Tensor]:
+        out = {}
+        for k, r in stf_drop_path_rates(self.drop_path_rate).items():
+            d = _draw_drop(r, B, device)
+            if d is not None:
+                out[k] = d
+        return out
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("SymmetricalTransFormer.forward expects [B,3,H,W]")
+        names, params = _named(self)
+        dev = x.device
+        nz = ny = drops = None
+        if self.training:
+            nz, ny = _train_noise(self._noise, x, 192, 384)
+            drops = self._drops if self._drops is not None else self.draw_drops(x.shape[0], dev)
+            drops = {k: v.to(dev, torch.float32).contiguous() for k, v in drops.items()}
+        ns, ms, ws = self.num_slices, self.max_support_slices, self.window_size
+
+        def runner(tape, xin, *ps):
+            return stf_forward(tape, dict(zip(names, ps)), xin, nz, ny, drops, ns, ms, ws)
+
+        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
+        return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
+
+    @classmethod
+    def from_state_dict(cls, state_dict):
+        net = cls()
         net.load_state_dict(state_dict)
         return net

@@ -1,4 +1,4 @@
 """compressai/zoo mirror restricted to the hot path (zoo/__init__.py:23-43)."""
-from .models import WACNN
+from .models import WACNN, SymmetricalTransFormer
 
-models = {"cnn": WACNN}
+models = {"cnn": WACNN, "stf": SymmetricalTransFormer}

@@ -1,0 +1,269 @@
+"""GPU parity of the `stf` (SymmetricalTransFormer) path: LayerNorm / Swin block / PatchMerging / PatchSplit against
+the committed reference fixtures (tests/golden/swin_*.npz, patch_*.npz) and the whole model forward / backward
+against tests/golden/stf_e2e.npz and the CPU oracle (oracle/stf_oracle.py).
+
+Layout: the reference works on tokens [B, H*W, C]; the HIP path keeps NCHW, so fixtures are transposed here.
+Tolerances: f32 everywhere; 3e-5 of the tensor max for forward values, 1e-4 for gradients with long reductions.
+Rounding discontinuity: as in test_gpu_wacnn.py (flips are counted, x_hat-dependent bounds widened per flip).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stf_oracle as S
+from oracle import wacnn_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def to_map(tok, H, W):
+    """[B, H*W, C] -> contiguous NCHW"""
+    B, L, C = tok.shape
+    return tok.reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def run_tape(fn, x, P, g):
+    """fn(tape, x, P) -> y on the GPU with backward seeded by g; returns (y, gx, {name: grad})."""
+    from icm_amd import engine as E
+    tape = E.Tape(need_grad=True)
+    xd = x.cuda()
+    Pd = {k: v.cuda() for k, v in P.items()}
+    y = fn(tape, xd, Pd)
+    tape.bind_grad(y, g.cuda().contiguous(), True)
+    tape.backward()
+    torch.cuda.synchronize()
+    grads = {k: tape.grad_of(v) for k, v in Pd.items()}
+    return y, tape.grad_of(xd), grads
+
+
+@pytest.mark.parametrize("shape,sliced", [((2, 48, 12, 8), False), ((3, 384, 4, 4), False), ((2, 96, 8, 8), True)])
+def test_layernorm_vs_torch(shape, sliced):
+    from icm_amd import engine as E
+    N, C, H, Wd = shape
+    x = W._u("ln.x", shape, -2.0, 3.0)
+    gamma, beta = 1.0 + W._u("ln.g", (C,), -0.3, 0.3), W._u("ln.b", (C,), -0.2, 0.2)
+    g = W._u("ln.dy", shape, -1.0, 1.0)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    yr = F.layer_norm(xr.permute(0, 2, 3, 1), (C,), gr, br, 1e-5).permute(0, 3, 1, 2)
+    yr.backward(g)
+    if sliced:   # input is a channel slice of a wider buffer (explicit batch stride)
+        big = torch.zeros((N, C + 32, H, Wd)).cuda()
+        big[:, 16:16 + C] = x.cuda()
+        xin = big[:, 16:16 + C]
+        y, gx, gp = None, None, None
+        tape = E.Tape(need_grad=True)
+        Pd = {"w": gamma.cuda(), "b": beta.cuda()}
+        y = E.layernorm(tape, xin, Pd["w"], Pd["b"])
+        tape.bind_grad(y, g.cuda(), True)
+        tape.backward()
+        gx, gp = tape.grad_of(xin), {k: tape.grad_of(v) for k, v in Pd.items()}
+    else:
+        y, gx, gp = run_tape(lambda t, xx, P: E.layernorm(t, xx, P["w"], P["b"]), x, {"w": gamma, "b": beta}, g)
+    assert rel(y, yr) < 3e-5
+    assert rel(gx, xr.grad) < 5e-5
+    assert rel(gp["w"], gr.grad) < 5e-5
+    assert rel(gp["b"], br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("tag,shift", [("swin_d48_shift2", 2), ("swin_d48_noshift", 0)])
+def test_swin_block_vs_reference_fixture(golden_dir, tag, shift):
+    from icm_amd import engine as E
+    f = load(golden_dir, tag)
+    H, Wd = 12, 8
+    skip = {"x", "g", "y", "gx", "dp"}
+    P = {"b." + k: v for k, v in f.items() if k not in skip and not k.startswith("g_") and isinstance(v, torch.Tensor)}
+    dp = f["dp"].cuda()
+    y, gx, gp = run_tape(lambda t, xx, Pd: E.swin_block(t, xx, Pd, "b", 3, 4, shift, dp), to_map(f["x"], H, Wd), P,
+                         to_map(f["g"], H, Wd))
+    assert rel(y, to_map(f["y"], H, Wd)) < 3e-5
+    assert rel(gx, to_map(f["gx"], H, Wd)) < 1e-4
+    for k in P:
+        assert rel(gp[k], f["g_" + k[2:]]) < 1e-4, k
+    # eval mode (no DropPath): residual adds are fused into the proj / fc2 epilogues -> check against the oracle
+    sd = {tag + "." + k[2:]: v for k, v in P.items()}
+    sd[tag + ".attn.relative_position_index"] = O.relative_position_index(4)
+    with torch.no_grad():
+        ref = S.swin_block(f["x"], H, Wd, sd, tag, 3, 4, shift, None)
+    y2, gx2, _ = run_tape(lambda t, xx, Pd: E.swin_block(t, xx, Pd, "b", 3, 4, shift, None), to_map(f["x"], H, Wd), P,
+                          to_map(f["g"], H, Wd))
+    assert rel(y2, to_map(ref, H, Wd)) < 3e-5
+
+
+@pytest.mark.parametrize("tag", ["patch_merge_d48", "patch_split_d96"])
+def test_patch_resample_vs_reference_fixture(golden_dir, tag):
+    from icm_amd import engine as E
+    f = load(golden_dir, tag)
+    H, Wd = 8, 12
+    skip = {"x", "g", "y", "gx"}
+    P = {"d." + k: v for k, v in f.items() if k not in skip and not k.startswith("g_") and isinstance(v, torch.Tensor)}
+    merge = tag.startswith("patch_merge")
+    Ho, Wo = (H // 2, Wd // 2) if merge else (2 * H, 2 * Wd)
+    fn = E.patch_merging if merge else E.patch_split
+    y, gx, gp = run_tape(lambda t, xx, Pd: fn(t, xx, Pd, "d"), to_map(f["x"], H, Wd), P, to_map(f["g"], Ho, Wo))
+    assert rel(y, to_map(f["y"], Ho, Wo)) < 3e-5
+    assert rel(gx, to_map(f["gx"], H, Wd)) < 1e-4
+    for k in P:
+        assert rel(gp[k], f["g_" + k[2:]]) < 1e-4, k
+
+
+@pytest.fixture(scope="module")
+def model():
+    from icm_amd.zoo import models
+    net = models["stf"]()
+    net.load_state_dict(W.make_stf_state_dict())
+    return net.to("cuda:0")
+
+
+def test_stf_state_dict_matches_reference_keys(golden_dir, model):
+    import json
+    with open(os.path.join(golden_dir, "stf_keys.json")) as fh:
+        ref = json.load(fh)
+    sd = model.state_dict()
+    assert [k for k, _, _ in ref] == list(sd.keys())
+    for k, shp, dt in ref:
+        assert list(sd[k].shape) == shp and str(sd[k].dtype) == "torch." + dt, k
+
+
+def test_stf_eval_forward_vs_reference_fixture(golden_dir, model):
+    from icm_amd import engine as E
+    from icm_amd.layers import _named
+    from icm_amd.models import stf_forward
+    f = load(golden_dir, "stf_e2e")
+    x = W._u("stf.x", (1, 3, 256, 256), 0.0, 1.0).cuda()
+    model.eval()
+    names, params = _named(model)
+    keep = {}
+    with torch.no_grad():
+        x_hat, y_lik, z_lik = stf_forward(E.Tape(need_grad=False), dict(zip(names, [p.detach() for p in params])), x,
+                                          keep=keep)
+    assert rel(keep["y"], f["y"]) < 1e-4
+    assert rel(keep["z"], f["z"]) < 1e-4
+    assert rel(keep["mu"][:, :32], f["mu"][:, :32]) < 1e-4
+    assert rel(z_lik, f["lik_z"]) < 1e-4
+    flips = (torch.round(keep["y"].cpu() - keep["mu"].cpu()) != torch.round(f["y"] - f["mu"])).sum().item()
+    print("rounding flips vs reference:", flips, "| fixture elements within 1e-4 of a half:", int(f["margin_y_lt_1e4"]))
+    assert flips <= int(f["margin_y_lt_1e4"]) + 2
+    out = model(x)
+    assert torch.equal(out["x_hat"], x_hat)
+    L = O.rd_loss(x.cpu(), {"x_hat": out["x_hat"].cpu(), "likelihoods": {k: v.cpu() for k, v in out["likelihoods"].items()}},
+                  float(f["lmbda"]))
+    assert abs(L["bpp_loss"].item() - f["bpp"].item()) <= 1e-4 * f["bpp"].item() + 5e-4 * flips
+    assert abs(L["mse_loss"].item() - f["mse"].item()) <= 1e-4 * f["mse"].item() + 2e-3 * flips
+    if flips == 0:
+        assert rel(out["x_hat"][0, :, 96:128, 160:192], f["x_hat_crop"]) < 1e-4
+
+
+def test_stf_synthesis_on_reference_latents(golden_dir, model):
+    """syn_layers + end_conv alone, fed the reference's own y_hat: no rounding involved -> tight bound"""
+    from icm_amd import engine as E
+    from icm_amd.layers import _named
+    from icm_amd.models import _basic_layer, STF_DEPTHS, STF_HEADS
+    from icm_amd.engine import VT
+    f = load(golden_dir, "stf_e2e")
+    names, params = _named(model)
+    P = dict(zip(names, [p.detach() for p in params]))
+    tape = E.Tape(need_grad=False)
+    with torch.no_grad():
+        ref = S.synthesis(f["y_hat"], W.make_stf_state_dict())
+        t = f["y_hat"].cuda()
+        for i in range(4):
+            t = _basic_layer(tape, P, f"syn_layers.{i}", t, STF_DEPTHS[3 - i], STF_HEADS[3 - i], 4,
+                             "split" if i < 3 else None, None)
+        t = E.conv2d(tape, VT(t), P["end_conv.0.weight"], P["end_conv.0.bias"], pad=2, pixel_shuffle=2)
+        out = E.conv2d(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
+    assert rel(out, ref) < 1e-4
+    assert rel(out[0, :, 96:128, 160:192], f["x_hat_crop"]) < 1e-4
+
+
+def test_stf_train_step_grads_vs_reference_fixture(golden_dir, model):
+    from icm_amd.losses import RateDistortionLoss
+    f = load(golden_dir, "stf_e2e")
+    B = 2
+    xt = W._u("stf.xt", (B, 3, 128, 128), 0.0, 1.0).cuda()
+    noise = {"z": W._u("stf.noise_z", (B, 192, 2, 2), -0.5, 0.5), "y": W._u("stf.noise_y", (B, 384, 8, 8), -0.5, 0.5)}
+    drops = {str(n): f["t_drops"][i] for i, n in enumerate(f["t_drop_names"])}
+    model.train()
+    model.inject_noise(noise, drops)
+    model.zero_grad()
+    out = model(xt)
+    crit = RateDistortionLoss(float(f["lmbda"]))(out, xt)
+    crit["loss"].backward()
+    model.inject_noise(None, None)
+    assert abs(crit["bpp_loss"].item() - f["t_bpp"].item()) <= 1e-4 * f["t_bpp"].item()
+    assert rel(out["likelihoods"]["z"], f["t_lik_z"]) < 1e-4
+    assert rel(out["likelihoods"]["y"], f["t_lik_y"]) < 1e-4
+    loss_rel = abs(crit["loss"].item() - f["t_loss"].item()) / f["t_loss"].item()
+    xh_rel = rel(out["x_hat"][:, :, 32:64, 64:96], f["t_x_hat_crop"])
+    print("train loss rel diff", loss_rel, "x_hat crop rel", xh_rel)
+    assert loss_rel < 5e-3
+    names = [str(n) for n in f["t_grad_names"]]
+    P = dict(model.named_parameters())
+    got = torch.tensor([0.0 if P[n].grad is None else P[n].grad.double().norm().item() for n in names]).double()
+    tot_ref = float(f["t_total_grad_norm"])
+    err = (got - f["t_grad_norms"].double()).abs().max().item() / tot_ref
+    print("worst per-tensor grad-norm error / total norm:", err)
+    assert err < 2e-2
+    flip_free = xh_rel < 1e-4
+    worst = 0.0
+    for k in f:
+        if k.startswith("t_g_"):
+            r = rel(P[k[4:]].grad, f[k])
+            worst = max(worst, r)
+            print(f"  grad {k[4:]}: rel {r:.2e}")
+    assert rel(P["entropy_bottleneck._matrix0"].grad, f["t_g_entropy_bottleneck._matrix0"]) < 1e-3
+    assert worst < (2e-4 if flip_free else 5e-2)
+    aux = model.aux_loss()
+    assert abs(aux.item() - f["t_aux"].item()) <= 1e-5 * f["t_aux"].item()
+
+
+def test_stf_train_grads_vs_oracle_small():
+    """64x64 input, oracle autograd as reference: every parameter gradient"""
+    from icm_amd.zoo import models
+    from icm_amd.losses import RateDistortionLoss
+    sd = W.make_stf_state_dict()
+    B = 2
+    x = W._u("stfs.x", (B, 3, 64, 64), 0.0, 1.0)
+    noise = {"z": W._u("stfs.nz", (B, 192, 1, 1), -0.5, 0.5), "y": W._u("stfs.ny", (B, 384, 4, 4), -0.5, 0.5)}
+    drops = {}
+    for name, rate in S.drop_path_rates().items():
+        if rate > 0:
+            drops[name] = (W._u("stfs.dp." + name, (2, B), 0.0, 1.0) < 1.0 - rate).float() / (1.0 - rate)
+    s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd.items()}
+    o = S.stf_forward(s, x, noise, drops)
+    Lr = O.rd_loss(x, o, 0.0067)
+    Lr["loss"].backward()
+    net = models["stf"]()
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    net.inject_noise(noise, drops)
+    out = net(x.cuda())
+    crit = RateDistortionLoss(0.0067)(out, x.cuda())
+    crit["loss"].backward()
+    assert abs(crit["bpp_loss"].item() - Lr["bpp_loss"].item()) <= 1e-4 * Lr["bpp_loss"].item()
+    tot = math.sqrt(sum((s[n].grad.double() ** 2).sum().item() for n, _ in net.named_parameters() if s[n].grad is not None))
+    bad = []
+    for n, p in net.named_parameters():
+        gr = s[n].grad if s[n].grad is not None else torch.zeros_like(s[n])
+        gg = p.grad.cpu() if p.grad is not None else torch.zeros_like(gr)
+        e = (gg - gr).double().norm().item() / tot
+        if e > 1e-3:
+            bad.append((n, e))
+    xr = rel(out["x_hat"], o["x_hat"])
+    print("x_hat rel diff", xr, "bad grads:", bad[:8])
+    if xr < 1e-4:   # no rounding flip happened: everything must match tightly
+        assert not bad

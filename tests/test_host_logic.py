@@ -133,3 +133,34 @@ def test_reference_error_behaviour(dry):
         EntropyBottleneck(8).quantize(torch.zeros(1), "bogus")
     with pytest.raises(ValueError):
         layers.Conv2d(8, 8, 3, padding=1)(torch.zeros(1, 4, 8, 8))
+
+
+def test_stf_tape_plumbing_dry_run(dry):
+    from icm_amd.zoo import models
+    torch.manual_seed(0)
+    net = models["stf"]().train()
+    x = torch.rand(2, 3, 64, 64)
+    out = net(x)
+    assert out["x_hat"].shape == (2, 3, 64, 64)
+    assert out["likelihoods"]["y"].shape == (2, 384, 4, 4) and out["likelihoods"]["z"].shape == (2, 192, 1, 1)
+    loss = out["x_hat"].sum() + out["likelihoods"]["y"].sum() + out["likelihoods"]["z"].sum()
+    loss.backward()
+    missing = [n for n, p in net.named_parameters() if p.grad is None and not n.endswith("quantiles")]
+    assert not missing, missing[:10]
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert p.grad.shape == p.shape, n
+    # 24 Swin blocks: one attention core each, two LayerNorms each (+ patch_embed + 3 merges + 3 splits)
+    assert dry.calls["icm_winattn_fwd"] == 24 and dry.calls["icm_winattn_bwd"] == 24
+    assert dry.calls["icm_layernorm_fwd"] == 24 * 2 + 1 + 6 and dry.calls["icm_layernorm_bwd"] == 24 * 2 + 1 + 6
+    assert dry.calls["icm_space_to_depth2"] == 6            # 3 PatchMerging gathers forward + 3 scatters backward
+    assert dry.calls["icm_gc_likelihood_ste_fwd"] == 12
+    # the first analysis and first synthesis block have drop-path rate 0 (fused residual epilogues); the other 22
+    # draw per-sample scales: 2 branches each, forward + backward
+    assert dry.calls["icm_residual_scale"] == 22 * 2 * 2
+
+
+def test_stf_rejects_non_default_architecture():
+    from icm_amd.models import SymmetricalTransFormer
+    with pytest.raises(NotImplementedError):
+        SymmetricalTransFormer(embed_dim=96)
