@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="time eval-mode forward only (reported separately)")
+    ap.add_argument("--model", default="cnn", choices=["cnn", "stf"], help="cnn = BASELINE.json headline (default); "
+                    "stf = configs[3], reported as an extra line")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +111,7 @@ def main():
     from icm_amd.zoo import models
     from icm_amd.trainer import Trainer
     torch.manual_seed(0)
-    net = models["cnn"]()
+    net = models[args.model]()
     sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
     tr = Trainer(net, lr=1e-4, aux_lr=1e-4, lmbda=0.0067, clip_max_norm=1.0, device=dev)
     g = torch.Generator(device=dev)
@@ -119,8 +121,8 @@ def main():
     def one():
         if args.fwd_only:
             from icm_amd import engine as E
-            from icm_amd.models import wacnn_forward
-            wacnn_forward(E.Tape(need_grad=False), tr.params(), x)
+            from icm_amd.models import stf_forward, wacnn_forward
+            (stf_forward if args.model == "stf" else wacnn_forward)(E.Tape(need_grad=False), tr.params(), x)
             return None
         return tr.step(x)
 
@@ -145,14 +147,18 @@ def main():
     if rank == 0:
         ips = world * BATCH_PER_GPU * args.steps / dt
         gflop = FWD_GFLOP_PER_IMG if args.fwd_only else STEP_GFLOP_PER_IMG
+        if args.model == "stf":   # stf forward 33.498 GMAC = 67.0 GFLOP/image
+            gflop = 67.0 if args.fwd_only else 3 * 67.0
         line = {
-            "metric": "images/sec (256x256) cnn-hyperprior (WACNN) " + ("forward" if args.fwd_only else "training step"),
+            "metric": ("images/sec (256x256) cnn-hyperprior (WACNN) " if args.model == "cnn" else
+                       "images/sec (256x256) stf (SymmetricalTransFormer) ") + ("forward" if args.fwd_only else "training step"),
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cnn (WACNN N=192 M=320) train step, lambda=0.0067 MSE, batch 16/GPU synthetic "
-                                   "256x256, Adam lr 1e-4 + aux Adam, clip 1.0" if not args.fwd_only else
-                                   "cnn (WACNN) eval forward, batch 16/GPU synthetic 256x256",
+            "config": {"workload": (("cnn (WACNN N=192 M=320)" if args.model == "cnn" else "stf (Swin, embed 48, 12 slices)") +
+                                    (" train step, lambda=0.0067 MSE, batch 16/GPU synthetic 256x256, Adam lr 1e-4 + "
+                                     "aux Adam, clip 1.0" if not args.fwd_only else
+                                     " eval forward, batch 16/GPU synthetic 256x256")),
                        "global_batch": world * BATCH_PER_GPU, "parallelism": f"dp{world}"},
             "roofline_step": {"bound": "mfma", "achieved": ips / world * gflop / 1e3, "peak": PEAK_F32_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": ips / world * gflop / 1e3 / PEAK_F32_MFMA_TFLOPS,

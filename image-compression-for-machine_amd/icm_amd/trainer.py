@@ -24,11 +24,12 @@ import torch.distributed as dist
 from . import _lib as L
 from . import engine as E
 from ._lib import check, ptr
-from .models import wacnn_forward
+from .models import SymmetricalTransFormer, stf_forward, wacnn_forward
 
 # bucket -> parameter-name prefixes, in the order their gradients complete during backward
-BUCKETS = [("g_s",), ("cc_mean_transforms", "cc_scale_transforms", "lrp_transforms"),
-           ("h_a", "h_mean_s", "h_scale_s", "entropy_bottleneck"), ("g_a",)]
+# (synthesis transform | slice chains | hyper path | analysis transform); names of the cnn and the stf model
+BUCKETS = [("g_s", "syn_layers", "end_conv"), ("cc_mean_transforms", "cc_scale_transforms", "lrp_transforms"),
+           ("h_a", "h_mean_s", "h_scale_s", "entropy_bottleneck"), ("g_a", "patch_embed", "layers")]
 
 
 class FlatParams:
@@ -153,11 +154,13 @@ class Trainer:
         if self.wg_every < 0:
             self.side = None
         self._eb = None
+        self.is_stf = isinstance(model, SymmetricalTransFormer)
+        self.lat_ch = 384 if self.is_stf else 320
 
     def params(self) -> Dict[str, torch.Tensor]:
         return self.flat.views
 
-    def step(self, x: torch.Tensor, noise: Optional[dict] = None) -> torch.Tensor:
+    def step(self, x: torch.Tensor, noise: Optional[dict] = None, drops: Optional[dict] = None) -> torch.Tensor:
         """one training iteration on this rank's shard x [B,3,H,W]; returns the device tensor
         [bpp, mse, loss, sumlog_y, sumlog_z, grad_sqnorm, aux_loss, -] (no host sync)."""
         f, dev = self.flat, self.device
@@ -167,7 +170,7 @@ class Trainer:
         B, _, H, W = x.shape
         if noise is None:
             nz = torch.rand((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev) - 0.5
-            ny = torch.rand((B, 320, H // 16, W // 16), dtype=torch.float32, device=dev) - 0.5
+            ny = torch.rand((B, self.lat_ch, H // 16, W // 16), dtype=torch.float32, device=dev) - 0.5
         else:
             nz, ny = noise["z"].to(dev).contiguous(), noise["y"].to(dev).contiguous()
         P = f.views
@@ -181,7 +184,13 @@ class Trainer:
         for n, _ in f.main:
             tape.bind_grad(P[n], f.gviews[n], False)
         marks = {}
-        x_hat, y_lik, z_lik = wacnn_forward(tape, P, x, nz, ny, bucket_marks=marks)
+        if self.is_stf:
+            if drops is None:   # stochastic depth, drawn per step like timm's DropPath (stf.py:145)
+                drops = self.model.draw_drops(B, dev)
+            drops = {k: v.to(dev, torch.float32).contiguous() for k, v in drops.items()}
+            x_hat, y_lik, z_lik = stf_forward(tape, P, x, nz, ny, drops, bucket_marks=marks)
+        else:
+            x_hat, y_lik, z_lik = wacnn_forward(tape, P, x, nz, ny, bucket_marks=marks)
         # ---- R-D loss forward + seeds (train.py:53-76)
         self.scal.zero_()
         check(lib.icm_rd_loss_fwd(ptr(x), ptr(x_hat), x.numel(), ptr(y_lik), y_lik.numel(), ptr(z_lik), z_lik.numel(),

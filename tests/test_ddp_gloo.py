@@ -39,7 +39,12 @@ def _worker(rank, world, port, q):
             assert b0 == a1
         assert sum(p.numel() for _, p in flat.main) == 75235779 - 192 * 3
         names0 = {n.split(".")[0] for n, _ in flat.main}
-        assert names0 == {p for b in BUCKETS for p in b}
+        assert names0 <= {p for b in BUCKETS for p in b} and len(flat.bucket_ranges) == len(BUCKETS)
+        # the stf model maps onto the same four buckets (synthesis | slice chains | hyper | analysis), none left over
+        sflat = FlatParams(models["stf"](), torch.device("cpu"))
+        assert len(sflat.bucket_ranges) == len(BUCKETS) and sflat.bucket_ranges[-1][1] == sflat.n_main
+        assert {n.split(".")[0] for n, _ in sflat.main} <= {p for b in BUCKETS for p in b}
+        assert all(b > a for a, b in sflat.bucket_ranges)
         # parameters are views of the flat buffer
         flat.p.fill_(1.5)
         assert all(float(p.data.flatten()[0]) == 1.5 for _, p in flat.main)

@@ -267,3 +267,56 @@ def test_stf_train_grads_vs_oracle_small():
     print("x_hat rel diff", xr, "bad grads:", bad[:8])
     if xr < 1e-4:   # no rounding flip happened: everything must match tightly
         assert not bad
+
+
+def test_stf_trainer_step_vs_oracle():
+    """native data-parallel step on the stf model: loss of step 1 and the 2-step parameter update == reference loop
+    semantics (train.py:188-214) evaluated on the oracle with the same injected noise / DropPath scales"""
+    from icm_amd.zoo import models
+    from icm_amd.trainer import Trainer
+    sd = W.make_stf_state_dict()
+    B = 2
+    x = W._u("stft.x", (B, 3, 64, 64), 0.0, 1.0)
+    noises = [{"z": W._u(f"stft.nz{i}", (B, 192, 1, 1), -0.5, 0.5), "y": W._u(f"stft.ny{i}", (B, 384, 4, 4), -0.5, 0.5)}
+              for i in range(2)]
+    drops = []
+    for i in range(2):
+        d = {}
+        for name, rate in S.drop_path_rates().items():
+            if rate > 0:
+                d[name] = (W._u(f"stft.dp{i}." + name, (2, B), 0.0, 1.0) < 1.0 - rate).float() / (1.0 - rate)
+        drops.append(d)
+    s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd.items()}
+    pnames = [k for k, v in s.items() if isinstance(v, torch.Tensor) and v.requires_grad and
+              k.rsplit(".", 1)[-1] not in ("pedestal", "bound", "target", "scale_bound")]
+    main = [n for n in pnames if not n.endswith(".quantiles")]
+    st = {n: (torch.zeros_like(s[n]), torch.zeros_like(s[n])) for n in pnames}
+    ref_losses = []
+    for it in range(2):
+        for n in pnames:
+            s[n].grad = None
+        out = S.stf_forward(s, x, noises[it], drops[it])
+        Lr = O.rd_loss(x, out, 0.0067)
+        Lr["loss"].backward()
+        ref_losses.append(Lr["loss"].item())
+        grads = [s[n].grad if s[n].grad is not None else torch.zeros_like(s[n]) for n in main]
+        O.clip_grad_norm_(grads, 1.0)
+        with torch.no_grad():
+            for n, g in zip(main, grads):
+                O.adam_step(s[n], g, st[n][0], st[n][1], it + 1, 1e-4)
+        aux = O.eb_aux_loss(s)
+        (gq,) = torch.autograd.grad(aux, [s["entropy_bottleneck.quantiles"]])
+        with torch.no_grad():
+            q = "entropy_bottleneck.quantiles"
+            O.adam_step(s[q], gq, st[q][0], st[q][1], it + 1, 1e-4)
+    net = models["stf"]()
+    net.load_state_dict(sd)
+    tr = Trainer(net, lr=1e-4, aux_lr=1e-4, lmbda=0.0067, clip_max_norm=1.0, device="cuda:0")
+    losses = [tr.step(x.cuda(), noises[it], drops[it])[2].item() for it in range(2)]
+    print("losses", losses, ref_losses)
+    assert abs(losses[0] - ref_losses[0]) <= 1e-4 * abs(ref_losses[0])
+    P = dict(net.named_parameters())
+    num = sum(((P[n].detach().cpu() - s[n].detach()).double() ** 2).sum().item() for n in pnames)
+    den = sum(((s[n].detach() - sd[n]).double() ** 2).sum().item() for n in pnames)
+    print("relative L2 error of the update:", math.sqrt(num / den))
+    assert math.sqrt(num / den) < 2e-2
