@@ -649,6 +649,7 @@ static int validate(const icm_conv_args& a) {
        a.epi == ICM_EPI_AXPY2) && !a.aux)
     return ICM_ERR_ARG;
   if (a.epi == ICM_EPI_AXPY2 && !a.aux2) return ICM_ERR_ARG;
+  if ((long long)a.N * a.x_bs * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   if (a.pixel_shuffle != 0 && a.pixel_shuffle != 2) return ICM_ERR_UNSUPPORTED;
   if (a.pixel_shuffle == 2 && (a.Cout % 4 != 0 || a.transposed)) return ICM_ERR_ARG;
   return ICM_OK;

@@ -364,11 +364,12 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
 
 extern "C" {
 
-int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a) {
+int64_t icm_wgrad_workspace_floats_grouped(const icm_wgrad_args* a, int n) {
   icm::WgPlan p;
-  if (!a || icm::plan_wgrad(*a, p)) return -1;
+  if (!a || n < 1 || icm::plan_wgrad(*a, p, n)) return -1;
   return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
 }
+int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a) { return icm_wgrad_workspace_floats_grouped(a, 1); }
 
 static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   using namespace icm;
@@ -388,6 +389,8 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   if ((long long)a->N * a->gb_bs * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   const int ntaps = a->KH * a->KW;
   const long long slab_all = (long long)p.nsplit * ntaps * a->Ca * a->Cb;
+  for (int i = 0; i < n; ++i)   // the slabs (+ bias partials) of this launch's split count must fit the caller's workspace
+    if (arr[i].ws_floats > 0 && arr[i].ws_floats < slab_all + (long long)p.nsplit * a->Ca) return ICM_ERR_ARG;
   WgDesc d;
   RedDesc r;
   for (int i = 0; i < WG_MAXG; ++i) {

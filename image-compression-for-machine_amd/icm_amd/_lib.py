@@ -38,7 +38,7 @@ class WgradArgs(C.Structure):
         ("gb", vp), ("gb_bs", i64), ("Cb", i32), ("H", i32), ("W", i32), ("act_b", i32),
         ("N", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
         ("dw", vp), ("ws", vp), ("accum", i32),
-        ("dbias", vp), ("accum_bias", i32),
+        ("dbias", vp), ("accum_bias", i32), ("ws_floats", i64),
     ]
 
 
@@ -65,7 +65,7 @@ _lib = None
 SYMBOLS = [
     "icm_strerror", "icm_version", "icm_conv_run", "icm_conv_run_grouped", "icm_conv2d_fwd", "icm_conv2d_dgrad",
     "icm_convT2d_fwd", "icm_convT2d_dgrad", "icm_packed_weight_floats", "icm_pack_weights", "icm_pack_weights_batch",
-    "icm_wgrad_workspace_floats", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
+    "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_layernorm_fwd", "icm_layernorm_bwd", "icm_space_to_depth2",
     "icm_residual_scale", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
@@ -85,6 +85,7 @@ def lib():
         L.icm_strerror.restype = C.c_char_p
         L.icm_packed_weight_floats.restype = i64
         L.icm_wgrad_workspace_floats.restype = i64
+        L.icm_wgrad_workspace_floats_grouped.restype = i64
         L.icm_packed_weight_floats.argtypes = [i32, i32, i32, i32]
         L.icm_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]
         L.icm_pack_weights_batch.argtypes = [C.POINTER(PackJob), i32, vp]
@@ -93,6 +94,7 @@ def lib():
         for n in ("icm_conv2d_fwd", "icm_conv2d_dgrad", "icm_convT2d_fwd", "icm_convT2d_dgrad"):
             getattr(L, n).argtypes = [C.POINTER(ConvArgs), vp]
         L.icm_wgrad_workspace_floats.argtypes = [C.POINTER(WgradArgs)]
+        L.icm_wgrad_workspace_floats_grouped.argtypes = [C.POINTER(WgradArgs), i32]
         L.icm_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
         L.icm_conv_wgrad_grouped.argtypes = [C.POINTER(WgradArgs), i32, vp]
         L.icm_channel_sum.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp]

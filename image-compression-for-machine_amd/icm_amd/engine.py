@@ -183,7 +183,7 @@ def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NON
     if n < 0:
         raise ValueError("icm wgrad: invalid geometry")
     ws = tape.workspace(n, gs.device)
-    a.ws = ptr(ws)
+    a.ws, a.ws_floats = ptr(ws), n
     check(L.lib().icm_conv_wgrad(C.byref(a), tape.st), "conv_wgrad")
 
 
@@ -228,7 +228,7 @@ def flush_wgrads(tape):
                 a.N, a.KH, a.KW, a.stride, a.pad = N, KH, KW, stride, pad
                 a.dw, a.accum = ptr(dw), accum
                 a.dbias, a.accum_bias = ptr(dbias), accum_bias
-            n = lib.icm_wgrad_workspace_floats(C.byref(arr[0]))
+            n = lib.icm_wgrad_workspace_floats_grouped(C.byref(arr[0]), len(chunk))
             if n < 0:
                 raise ValueError("icm wgrad: invalid geometry")
             n = (n + 63) // 64 * 64
@@ -241,7 +241,7 @@ def flush_wgrads(tape):
             else:
                 ws = tape.workspace(n * len(chunk), chunk[0][1].device)
             for j, a in enumerate(arr):
-                a.ws = ptr(ws) + 4 * n * j
+                a.ws, a.ws_floats = ptr(ws) + 4 * n * j, n
             check(lib.icm_conv_wgrad_grouped(arr, len(chunk), st), "conv_wgrad_grouped")
 
 

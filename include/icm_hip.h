@@ -108,8 +108,12 @@ typedef struct icm_wgrad_args {
   int N, KH, KW, stride, pad;
   float* dw; float* ws; int accum;
   float* dbias; int accum_bias;   /* optional: dbias[a] (+)= sum_{n,p} actS(gs[n,a,p]) (conv bias gradient, fused) */
+  int64_t ws_floats;              /* capacity of ws in floats; 0 = unchecked. Too small -> ICM_ERR_ARG, nothing launched */
 } icm_wgrad_args;
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a);
+/* workspace PER PROBLEM when n problems of this geometry are issued by one icm_conv_wgrad_grouped call (the pixel
+ * split count, hence the slab size, depends on how many problems share the launch) */
+int64_t icm_wgrad_workspace_floats_grouped(const icm_wgrad_args* a, int n);
 int icm_conv_wgrad(const icm_wgrad_args* a, void* stream);
 /* up to 32 weight-gradient problems of identical geometry in one launch pair (deferred, batched wgrads: a
  * weight gradient has no consumer but the optimiser, so the 150 small slice-chain wgrads are collected during

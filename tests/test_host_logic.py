@@ -39,6 +39,18 @@ def test_host_planning_entry_points():
     a.stride, a.pad = 2, 2
     n = L.icm_wgrad_workspace_floats(ctypes.byref(a))
     assert n > 0 and n % 192 == 0
+    # the pixel-split count (hence the slab size) depends on how many problems share a grouped launch
+    b = _lib.WgradArgs()
+    b.gs, b.gb = 1, 1
+    b.Ca, b.OH, b.OW, b.Cb, b.H, b.W, b.N = 1536, 16, 16, 384, 16, 16, 16
+    b.KH = b.KW = 1
+    b.stride, b.pad = 1, 0
+    sizes = {k: L.icm_wgrad_workspace_floats_grouped(ctypes.byref(b), k) for k in (1, 6)}
+    assert sizes[1] == L.icm_wgrad_workspace_floats(ctypes.byref(b)) and sizes[6] > sizes[1]
+    # a workspace that is too small for the launch's split count is refused before anything is launched
+    b.dw, b.ws, b.ws_floats = 1, 1, sizes[1]
+    arr = (_lib.WgradArgs * 6)(*[b] * 6)
+    assert L.icm_conv_wgrad_grouped(arr, 6, None) == 1
     a.OH = 63  # inconsistent geometry -> rejected like a shape error
     assert L.icm_wgrad_workspace_floats(ctypes.byref(a)) == -1
     # argument validation happens before any launch: NULL pointers / bad stride are refused on CPU too
@@ -58,7 +70,8 @@ class _FakeLib:
         self.calls = {}
 
     def __getattr__(self, name):
-        if name in ("icm_packed_weight_floats", "icm_wgrad_workspace_floats", "icm_strerror"):
+        if name in ("icm_packed_weight_floats", "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped",
+                    "icm_strerror"):
             return getattr(self._real, name)
 
         def f(*a):
