@@ -52,44 +52,94 @@ struct ConvDesc {
   int tapoff[ICM_MAX_TAPS];   // dword entries: read with s_load (a 16-bit entry forces a VMEM load + vmcnt(0))
 };
 
-__device__ __forceinline__ void store_tile(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot,
-                                                     int h, int n, int oy, int ox, bool pvalid) {
-  const long long plane = (long long)d.OHf * d.OWf;
+// Epilogue of one 32x32 accumulator tile.  The fused-neighbour kind is a template parameter so that the 16 rows
+// form ONE basic block: all operand loads (bias, residual, aux, old value) are issued back to back and waited for
+// once, instead of a load -> wait -> store chain per element.
+template <int EPI, int half>
+__device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot, int h,
+                                             int n, int oy, int ox, bool pvalid) {
+  const int plane = d.OHf * d.OWf;
+  constexpr bool kRes = EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU;
+  constexpr bool kAux = EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN || EPI == ICM_EPI_MUL_DGELU ||
+                        EPI == ICM_EPI_AXPY2 || EPI == ICM_EPI_LRP;
+  float* yb = P.y + n * d.y_bs;
+  const float* resb = kRes ? P.res + n * d.res_bs : nullptr;
+  const float* auxb = kAux ? P.aux + n * d.aux_bs : nullptr;
+  const float* aux2b = (EPI == ICM_EPI_AXPY2) ? P.aux2 + n * d.aux2_bs : nullptr;
+  float* y2b = P.y2 ? P.y2 + n * d.y2_bs : nullptr;
+  const bool has_bias = P.bias != nullptr;
+  // rows in two halves of 8: bounds the live registers of the load batch (the kernel's VGPR budget sets occupancy)
+  {
+    int off[8];
+    bool ok[8];
+    float bv[8], rv[8], av[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (!pvalid || co >= d.Cout) continue;
-    long long pix;
-    if (d.ps2) {
-      pix = (long long)(co >> 2) * plane + (long long)(oy * 2 + ((co >> 1) & 1)) * d.OWf + ox * 2 + (co & 1);
-    } else {
-      pix = (long long)co * plane + (long long)oy * d.OWf + ox;
+    for (int q = 0; q < 8; ++q) {
+      const int r = half * 8 + q;
+      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      ok[q] = pvalid && co < d.Cout;
+      off[q] = d.ps2 ? (co >> 2) * plane + (oy * 2 + ((co >> 1) & 1)) * d.OWf + ox * 2 + (co & 1)
+                     : co * plane + oy * d.OWf + ox;
+      bv[q] = (has_bias && ok[q]) ? P.bias[co] : 0.0f;
+      if constexpr (kRes) rv[q] = ok[q] ? resb[off[q]] : 0.0f;
+      if constexpr (kAux) av[q] = ok[q] ? auxb[off[q]] : 0.0f;
+      if constexpr (EPI == ICM_EPI_AXPY2) rv[q] = ok[q] ? aux2b[off[q]] : 0.0f;
     }
-    float v = acc[r];
-    if (P.bias) v += P.bias[co];
-    switch (d.epi) {
-      case ICM_EPI_RES: v += P.res[n * d.res_bs + pix]; break;
-      case ICM_EPI_RES_GELU: v += gelu_f(P.res[n * d.res_bs + pix]); break;
-      case ICM_EPI_GDN: {
-        if (P.y2) P.y2[n * d.y2_bs + pix] = v;
-        v = P.aux[n * d.aux_bs + pix] * rsqrtf(v);
-      } break;
-      case ICM_EPI_IGDN: {
-        if (P.y2) P.y2[n * d.y2_bs + pix] = v;
-        v = P.aux[n * d.aux_bs + pix] * sqrtf(v);
-      } break;
-      case ICM_EPI_MUL_DGELU: v *= dgelu_f(P.aux[n * d.aux_bs + pix]); break;
-      case ICM_EPI_AXPY2: v = P.aux2[n * d.aux2_bs + pix] + 2.0f * P.aux[n * d.aux_bs + pix] * v; break;
-      case ICM_EPI_LRP: {
-        const float t = tanhf(v);
-        if (P.y2) P.y2[n * d.y2_bs + pix] = t;
-        v = P.aux[n * d.aux_bs + pix] + 0.5f * t;
-      } break;
-      default: break;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      v[q] = acc[half * 8 + q] + bv[q];
+      if constexpr (EPI == ICM_EPI_RES) v[q] += rv[q];
+      if constexpr (EPI == ICM_EPI_RES_GELU) v[q] += gelu_f(rv[q]);
+      if constexpr (EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN) {
+        if (y2b && ok[q]) y2b[off[q]] = v[q];
+        v[q] = av[q] * (EPI == ICM_EPI_GDN ? rsqrtf(v[q]) : sqrtf(v[q]));
+      }
+      if constexpr (EPI == ICM_EPI_MUL_DGELU) v[q] *= dgelu_f(av[q]);
+      if constexpr (EPI == ICM_EPI_AXPY2) v[q] = rv[q] + 2.0f * av[q] * v[q];
+      if constexpr (EPI == ICM_EPI_LRP) {
+        const float t = tanhf(v[q]);
+        if (y2b && ok[q]) y2b[off[q]] = t;
+        v[q] = av[q] + 0.5f * t;
+      }
     }
-    float* yp = P.y + n * d.y_bs + pix;
-    if (d.accum) v += *yp;
-    *yp = v;
+    if (d.accum) {   // gradient accumulation: one more batched read of the destination
+      float old[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) old[q] = ok[q] ? yb[off[q]] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += old[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (ok[q]) yb[off[q]] = v[q];
+  }
+}
+template <int EPI>
+__device__ __forceinline__ void store_tile_e(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot, int h,
+                                             int n, int oy, int ox, bool pvalid) {
+  store_half_e<EPI, 0>(d, P, acc, cot, h, n, oy, ox, pvalid);
+  store_half_e<EPI, 1>(d, P, acc, cot, h, n, oy, ox, pvalid);
+}
+
+// all tiles of one MFMA wave for one epilogue kind (the kind is dispatched once, outside the unrolled tile loops)
+template <int EPI, int TCO, int TPX>
+__device__ __forceinline__ void epilogue_all(const ConvDesc& d, const ConvPtrs& P, const f32x16 (&acc)[TCO][TPX], int cot0,
+                                             int wpx, int h, int l31, int n0, int oy0, int ox0) {
+  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+#pragma unroll
+  for (int tp = 0; tp < TPX; ++tp) {
+    const int p = (wpx * TPX + tp) * 32 + l31;
+    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
+    const int n = n0 + ti, oyv = oy0 + ty, oxv = ox0 + tx;
+    const bool pvalid = (n < d.pg.N) && (oyv < d.OHv) && (oxv < d.OWv);
+    const int oy = oyv * d.out_sy + d.out_oy, ox = oxv * d.out_sx + d.out_ox;
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+      const int cot = cot0 + a;
+      if (cot < d.ncot) store_tile_e<EPI>(d, P, acc[a][tp], cot, h, n, oy, ox, pvalid);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -98,7 +148,7 @@ __device__ __forceinline__ void store_tile(const ConvDesc& d, const ConvPtrs& P,
 // MFMA and VALU/VMEM are separate pipes per SIMD, so with one MFMA wave and one loader wave per SIMD the
 // staging cost disappears behind the 64-cycle v_mfma_f32_32x32x2_f32 issue interval.
 template <int WCO, int WPX, int TCO, int TPX>
-__global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
+__global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(WCO * WPX == 4, "4 MFMA waves per workgroup");
   constexpr int BCO_T = WCO * TCO;
@@ -125,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
   if (loader) {
     const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
     PlaneMap pm;
+
     if (pg.vec4) {
       plane_map_init_v4(pm, pg, n0, iyb, ixb, lane);
       stage_planes_v4<8>(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
@@ -174,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
 
   const f32x4* wp4 = reinterpret_cast<const f32x4*>(P.wp);
   const int cot0 = cb * BCO_T + wco * TCO;
+
   int wl[TCO];  // per-lane fragment index of co tile a at Q = 0
 #pragma unroll
   for (int a = 0; a < TCO; ++a) wl[a] = min(cot0 + a, d.ncot - 1) * 64 + lane;
@@ -343,20 +395,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_kernel(const ConvDesc d) {
 
   }
 
-  // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h
-#pragma unroll
-  for (int tp = 0; tp < TPX; ++tp) {
-    const int p = (wpx * TPX + tp) * 32 + l31;
-    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
-    const int n = n0 + ti, oyv = oy0 + ty, oxv = ox0 + tx;
-    const bool pvalid = (n < pg.N) && (oyv < d.OHv) && (oxv < d.OWv);
-    const int oy = oyv * d.out_sy + d.out_oy, ox = oxv * d.out_sx + d.out_ox;
-#pragma unroll
-    for (int a = 0; a < TCO; ++a) {
-      const int cot = cot0 + a;
-      if (cot < d.ncot) store_tile(d, P, acc[a][tp], cot, h, n, oy, ox, pvalid);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+  // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h.  The epilogue kind is
+  // dispatched ONCE (uniform branch) around the fully unrolled tile loops.
+  switch (d.epi) {
+    case ICM_EPI_RES: epilogue_all<ICM_EPI_RES, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_RES_GELU: epilogue_all<ICM_EPI_RES_GELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_GDN: epilogue_all<ICM_EPI_GDN, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_IGDN: epilogue_all<ICM_EPI_IGDN, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_MUL_DGELU: epilogue_all<ICM_EPI_MUL_DGELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_AXPY2: epilogue_all<ICM_EPI_AXPY2, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_LRP: epilogue_all<ICM_EPI_LRP, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    default: epilogue_all<ICM_EPI_NONE, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
   }
 }
 
