@@ -653,6 +653,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
               (bg.CS % 4) == 0 && (bg.PWrow % 4) == 0 && (bg.PP % 4) == 0;
     for (int gi = 0; gi < ngroups; ++gi) v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[gi].x) & 15) == 0);
     pg.vec4 = v4 ? 1 : 0;
+    set_v4_pack(pg);
   }
   d.Cout = a.Cout;
   d.ps2 = a.pixel_shuffle == 2;
@@ -698,7 +699,7 @@ static int validate(const icm_conv_args& a) {
        a.epi == ICM_EPI_AXPY2) && !a.aux)
     return ICM_ERR_ARG;
   if (a.epi == ICM_EPI_AXPY2 && !a.aux2) return ICM_ERR_ARG;
-  if ((long long)a.N * a.x_bs * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
+  if (((long long)a.N * a.x_bs + 8LL * a.H * a.W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   if (a.pixel_shuffle != 0 && a.pixel_shuffle != 2) return ICM_ERR_UNSUPPORTED;
   if (a.pixel_shuffle == 2 && (a.Cout % 4 != 0 || a.transposed)) return ICM_ERR_ARG;
   return ICM_OK;

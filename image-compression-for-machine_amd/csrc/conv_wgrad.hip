@@ -175,52 +175,51 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
   const int pe_lane = d.pe[lane & 31];   // pixel-pair offsets live in one VGPR; v_readlane picks entry kp
+  // A tile of accumulator i: tile q = wave + 4*i has ta = (q % (TA*TB)) / TB, which is `i` for the 4x4 (1x1-conv)
+  // configuration and wave-uniform otherwise (TA*TB divides 4) -> no per-MFMA operand select, one A read per pair
+  constexpr bool kPerAcc = (TA * TB == 16);
+  static_assert(kPerAcc ? (NACC == 4 && TA == 4) : (4 % (TA * TB) == 0), "tile -> A-row mapping");
+  constexpr int NA = kPerAcc ? TA : 1;
+  const int ta_w = kPerAcc ? 0 : (wave % (TA * TB)) / TB;
   __syncthreads();  // tile 0 staged
-  const int nkp = npx >> 1;
+  const int nkp = npx >> 1;   // even (npx is 16 / 32 / 64)
   for (int it = 0; it < niter; ++it) {
     const float* gsT = smem + (it & 1) * bufsz;
     const float* gbP = gsT + gs_sz;
-    const float* arow = gsT + l31 * grow + h;
-    // software pipeline over pixel pairs: fragments of kp+1 are in flight while the MFMAs of kp issue
-    float av_n[TA], bv_n[NACC];
-    {
-      const int po = __builtin_amdgcn_readlane(pe_lane, 0);
+    const float* arow = gsT + (ta_w * 32 + l31) * grow + h;
+    // Two explicit register sets (ping-pong), loop unrolled by two pixel pairs: the fragments of pair kp+1 are
+    // fetched while the MFMAs of pair kp issue and nothing is copied between iterations, so no s_waitcnt ever
+    // waits on an LDS read issued in the same half-iteration.
+    float avA[NA], bvA[NACC], avB[NA], bvB[NACC];
+    auto fetch = [&](float (&av)[NA], float (&bv)[NACC], int kn) {
+      const int po = __builtin_amdgcn_readlane(pe_lane, kn);
 #pragma unroll
-      for (int ta = 0; ta < TA; ++ta) av_n[ta] = arow[ta * 32 * grow];
+      for (int u = 0; u < NA; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) bv_n[i] = gbP[boffs[i] + po];
-    }
-    for (int kp = 0; kp < nkp; ++kp) {
-      float av[TA], bv[NACC];
+      for (int i = 0; i < NACC; ++i) bv[i] = gbP[boffs[i] + po];
+    };
+    auto mma = [&](const float (&av)[NA], const float (&bv)[NACC]) {
 #pragma unroll
-      for (int ta = 0; ta < TA; ++ta) av[ta] = av_n[ta];
+      for (int i = 0; i < NACC; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kPerAcc ? i : 0], bv[i], acc[i], 0, 0, 0);
+    };
+    fetch(avA, bvA, 0);
+    for (int kp = 0; kp < nkp; kp += 2) {
+      fetch(avB, bvB, kp + 1);
+      mma(avA, bvA);
 #pragma unroll
-      for (int i = 0; i < NACC; ++i) bv[i] = bv_n[i];
-      {  // branch-free prefetch (the last iteration re-reads its own fragments): one basic block, so the
-         // scheduler can slot the LDS reads between MFMAs
-        const int kn = min(kp + 1, nkp - 1);
-        const int po = __builtin_amdgcn_readlane(pe_lane, kn);
-#pragma unroll
-        for (int ta = 0; ta < TA; ++ta) av_n[ta] = arow[ta * 32 * grow + 2 * kn];
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) bv_n[i] = gbP[boffs[i] + po];
+      for (int i = 0; i < NACC; ++i) {   // one MFMA, then the address VALU + LDS reads of the other set
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
-#pragma unroll
-      for (int i = 0; i < NACC; ++i) {
-        // no branch: tiles beyond this wave's share recompute tile 0 into an accumulator that is never stored
-        float a = av[0];
-#pragma unroll
-        for (int ta = 1; ta < TA; ++ta) a = (tsel[i] == ta) ? av[ta] : a;
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[i], acc[i], 0, 0, 0);
-      }
-      // issue order: one MFMA, then (while the matrix pipe is busy for 64 cycles) the VALU address math and one
-      // LDS read of the NEXT pixel pair -- the wave is in-order, so reads placed after the MFMA block would wait
+      fetch(avA, bvA, min(kp + 2, nkp - 1));   // the last fetch re-reads the final pair (never used)
+      mma(avB, bvB);
 #pragma unroll
       for (int i = 0; i < NACC; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-        if (i < TA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
     __syncthreads();
@@ -386,7 +385,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
         b.act_s != a->act_s || b.act_b != a->act_b || b.gs_bs != a->gs_bs || b.gb_bs != a->gb_bs)
       return ICM_ERR_ARG;
   }
-  if ((long long)a->N * a->gb_bs * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
+  if (((long long)a->N * a->gb_bs + 8LL * a->H * a->W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   const int ntaps = a->KH * a->KW;
   const long long slab_all = (long long)p.nsplit * ntaps * a->Ca * a->Cb;
   for (int i = 0; i < n; ++i)   // the slabs (+ bias partials) of this launch's split count must fit the caller's workspace
@@ -419,6 +418,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
       g4 = g4 && ((reinterpret_cast<uintptr_t>(arr[i].gs) & 15) == 0);
     }
     pg.vec4 = v4 ? 1 : 0;
+    set_v4_pack(pg);
     d.gs_vec4 = g4 ? 1 : 0;
   }
   d.Ca = a->Ca; d.OH = a->OH; d.OW = a->OW; d.act_s = a->act_s;

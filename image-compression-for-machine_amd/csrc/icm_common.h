@@ -55,7 +55,21 @@ struct PatchGeom {
   int H, W, N, C, act;
   long long bs;
   int vec4;   // halo-free, 4-pixel-aligned patch: stage with 16-byte loads / LDS stores (host-checked)
+  int v4R, v4P2;   // vec4 with a small plane: one load instruction covers v4R channels, v4P2 lanes each (set_v4_pack)
 };
+// vec4 staging of small planes (1x1 convolutions on 64..128-pixel tiles fill only 16..32 of the 64 lanes with one
+// channel): pack R = 64 / P2 channels into every load instruction, P2 = lanes per channel (power of two >= plane4)
+inline void set_v4_pack(PatchGeom& g) {
+  g.v4R = 1;
+  g.v4P2 = 64;
+  if (!g.vec4) return;
+  const int plane4 = g.TIPH * (g.PW >> 2);
+  if (plane4 > 32) return;
+  int p2 = 1;
+  while (p2 < plane4) p2 <<= 1;
+  g.v4P2 = p2;
+  g.v4R = 64 / p2;
+}
 // Plane-sweep staging: a loader wave owns whole channels; its 64 lanes sweep the (TI x PH x PW) plane of the
 // patch linearly.  The per-lane plane offsets (global and LDS) depend only on the tile, so they are computed
 // once (PlaneMap) and every channel afterwards costs one address add, one load and one LDS store per element,
@@ -64,9 +78,11 @@ struct PatchGeom {
 struct PlaneMap {
   int goff[ICM_MAXJ];   // offset inside the channel plane (incl. image offset n*bs), -1 = zero fill
   int loff[ICM_MAXJ];   // offset inside the LDS channel slab, -1 = beyond the plane
+  int lc;               // vec4 channel packing: this lane's channel inside a group of v4R channels (else 0)
 };
 __device__ __forceinline__ void plane_map_init(PlaneMap& m, const PatchGeom& g, int n0, int iyb, int ixb, int lane) {
   const int plane = g.TIPH * g.PW;
+  m.lc = 0;
 #pragma unroll
   for (int j = 0; j < ICM_MAXJ; ++j) {
     const int e = lane + 64 * j;
@@ -93,30 +109,38 @@ __device__ __forceinline__ void plane_map_init(PlaneMap& m, const PatchGeom& g, 
 __device__ __forceinline__ void plane_map_init_v4(PlaneMap& m, const PatchGeom& g, int n0, int iyb, int ixb, int lane) {
   const int pw4 = g.PW >> 2;
   const int plane4 = g.TIPH * pw4;
+  const bool packed = g.v4R > 1;
+  m.lc = packed ? lane / g.v4P2 : 0;
+  const int lane_e = packed ? lane - m.lc * g.v4P2 : lane;
+  const int HWb = g.H * g.W * 4;
 #pragma unroll
   for (int j = 0; j < ICM_MAXJ; ++j) {
-    const int e = lane + 64 * j;
+    const int e = lane_e + 64 * j;
     m.goff[j] = -1;
     m.loff[j] = -1;
-    if (e < plane4) {
+    if (e < plane4 && !(packed && j > 0)) {
       const int r = e / pw4;
       const int px = (e - r * pw4) << 2;
       const int ti = r / g.PH;
       const int py = r - ti * g.PH;
       const int n = n0 + ti, iy = iyb + py, ix = ixb + px;
       if (n < g.N && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-        m.goff[j] = ((int)((long long)n * g.bs) + iy * g.W + ix) * 4;
-      m.loff[j] = (ti * g.PP + py * g.PWrow + px) * 4;
+        m.goff[j] = ((int)((long long)n * g.bs) + iy * g.W + ix) * 4 + m.lc * HWb;
+      m.loff[j] = (ti * g.PP + py * g.PWrow + px) * 4 + m.lc * g.CS * 4;
     }
   }
 }
+// stage local channels of the patch: loader wave lw takes channel GROUPS lw, lw+4, ... (a group = v4R consecutive
+// channels moved by one load instruction; v4R = 1 unless the plane is small)
 template <int NJR, int MJ>
 __device__ __forceinline__ void stage_planes_t_v4(const float* __restrict__ src, const PlaneMap& m,
                                                   const PatchGeom& g, int c0, int nch, float* __restrict__ dst,
                                                   int lw) {
   constexpr int CPB = MJ / NJR;
   const long long HWb = (long long)g.H * g.W * 4;
-  const int nk = (nch - lw + 3) >> 2;
+  const int R = g.v4R;
+  const int ngroups = (nch + R - 1) / R;
+  const int nk = (ngroups - lw + 3) >> 2;
   const char* srcb = reinterpret_cast<const char*>(src);
   char* dstb = reinterpret_cast<char*>(dst);
   for (int kb = 0; kb < nk; kb += CPB) {
@@ -124,19 +148,21 @@ __device__ __forceinline__ void stage_planes_t_v4(const float* __restrict__ src,
 #pragma unroll
     for (int u = 0; u < CPB * NJR; ++u) {
       const int k = kb + u / NJR, j = u % NJR;
-      const int c = c0 + lw + 4 * k;
-      const char* base = srcb + (long long)c * HWb;
-      if (k < nk && c < g.C && m.goff[j] >= 0) v[u] = *reinterpret_cast<const f32x4*>(base + m.goff[j]);
+      const int cl = (lw + 4 * k) * R;            // first local channel of the group (wave-uniform)
+      const char* base = srcb + (long long)(c0 + cl) * HWb;
+      if (k < nk && cl + m.lc < nch && c0 + cl + m.lc < g.C && m.goff[j] >= 0)
+        v[u] = *reinterpret_cast<const f32x4*>(base + m.goff[j]);
       else v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
 #pragma unroll
     for (int u = 0; u < CPB * NJR; ++u) {
       const int k = kb + u / NJR, j = u % NJR;
-      if (k < nk && m.loff[j] >= 0) {
+      const int cl = (lw + 4 * k) * R;
+      if (k < nk && cl + m.lc < nch && m.loff[j] >= 0) {
         f32x4 w;
         w[0] = apply_act(v[u][0], g.act); w[1] = apply_act(v[u][1], g.act);
         w[2] = apply_act(v[u][2], g.act); w[3] = apply_act(v[u][3], g.act);
-        char* o = dstb + (lw + 4 * k) * g.CS * 4 + m.loff[j];
+        char* o = dstb + cl * g.CS * 4 + m.loff[j];
         if ((g.CS & 3) == 0) {
           *reinterpret_cast<f32x4*>(o) = w;
         } else {   // odd channel stride (conflict-free wgrad B fragments): four dword stores
@@ -193,6 +219,7 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, cons
   else if (nj == 3) stage_planes_t<3, MJ>(src, m, g, c0, nch, dst, lw);
   else if (nj == 4) stage_planes_t<4, MJ>(src, m, g, c0, nch, dst, lw);
   else if (nj <= 6) stage_planes_t<6, MJ>(src, m, g, c0, nch, dst, lw);
+  else if (nj <= 8) stage_planes_t<8, 16>(src, m, g, c0, nch, dst, lw);   // two channels (16 loads) in flight
   else stage_planes_t<12, (MJ < 12 ? 12 : MJ)>(src, m, g, c0, nch, dst, lw);
 }
 

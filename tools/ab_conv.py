@@ -19,3 +19,16 @@ for idx in range(len(SHAPES)):
     ms = min(timeit(lambda: E.conv2d(tape, VT(x), w, b, out=y, **kw), iters=10) for _ in range(3))
     out.append(f"{ms*1e3:7.1f}")
 print(os.path.basename(_lib.LIB_PATH).ljust(22), " ".join(out), flush=True)
+out = []
+for idx in range(len(SHAPES)):
+    name, N, Cin, H, W, Cout, k, s, tr = SHAPES[idx]
+    if tr:
+        continue
+    x = torch.randn(N, Cin, H, W, device=dev)
+    OH = (H + 2 * (k // 2) - k) // s + 1
+    dy = torch.randn(N, Cout, OH, OH, device=dev)
+    gw = torch.empty(Cout, Cin, k, k, device=dev); gb = torch.empty(Cout, device=dev)
+    tape = E.Tape(need_grad=False)
+    ms = min(timeit(lambda: E.wgrad_launch(tape, dy, x, gw, Ca=Cout, Cb=Cin, KH=k, KW=k, stride=s, pad=k // 2, dbias=gb), iters=10) for _ in range(3))
+    out.append(f"{ms*1e3:7.1f}")
+print((os.path.basename(_lib.LIB_PATH) + " wgrad").ljust(22), " ".join(out), flush=True)
