@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
 
   if (loader) {
+    __builtin_amdgcn_s_setprio(3);   // loaders are latency-critical and issue little: let them win arbitration
     const int ltid = tid - 256;
     const bool do_bias = G.dbias_ws != nullptr && bt == 0 && tg == 0;
     float bsum[TA * 8];
