@@ -420,57 +420,66 @@ struct PackDesc {
   short tapidx[ICM_MAX_TAPS];
 };
 
-__global__ void pack_weights_kernel(const PackDesc d) {
-  const long long total = (long long)d.nchunks * d.ntaps * d.ncot * 256;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
-    long long q = i >> 8;
-    const int cot = (int)(q % d.ncot);
-    q /= d.ncot;
-    const int t = (int)(q % d.ntaps);
-    const int chunk = (int)(q / d.ntaps);
-    const int co = cot * 32 + (lane & 31), ci = chunk * 8 + 2 * j + (lane >> 5);
+// One unit = (32-co tile, 8-ci chunk): the 8 x 32 x KHW source block is read with coalesced row segments into LDS
+// (row stride padded to an odd number of words: conflict-free transposed reads), then written out in fragment order
+// with one 16-byte store per lane per tap.  The canonical layouts differ only in which index is the contiguous row:
+// W[co][ci][khw] (src_out_major: 32 rows of 8*KHW) or W[ci][co][khw] (8 rows of 32*KHW).
+#define ICM_PACK_LDS (8 * 32 * ICM_MAX_TAPS + 64)
+__device__ __forceinline__ void pack_unit(const PackDesc& d, int cot, int chunk, float* lds) {
+  const int KHW = d.KHW, tid = threadIdx.x;
+  const int co0 = cot * 32, ci0 = chunk * 8;
+  int rows, rlen, rstride;
+  if (d.src_out_major) { rows = 32; rlen = 8 * KHW; } else { rows = 8; rlen = 32 * KHW; }
+  rstride = rlen | 1;
+  for (int e = tid; e < rows * rlen; e += blockDim.x) {
+    const int r = e / rlen, c = e - r * rlen;
     float v = 0.0f;
-    if (co < d.Co && ci < d.Ci) {
-      const long long src = d.src_out_major ? ((long long)co * d.Ci + ci) : ((long long)ci * d.Co + co);
-      v = d.w[src * d.KHW + d.tapidx[t]];
-      if (d.nonneg) {
-        v = fmaxf(v, d.bound);
-        v = v * v - d.pedestal;
-      }
+    if (d.src_out_major) {
+      const int co = co0 + r, ci = ci0 + c / KHW;
+      if (co < d.Co && ci < d.Ci) v = d.w[((long long)co * d.Ci + ci0) * KHW + c];
+    } else {
+      const int ci = ci0 + r, co = co0 + c / KHW;
+      if (ci < d.Ci && co < d.Co) v = d.w[((long long)ci * d.Co + co0) * KHW + c];
     }
-    d.wp[i] = v;
+    if (d.nonneg) {
+      v = fmaxf(v, d.bound);
+      v = v * v - d.pedestal;
+    }
+    lds[r * rstride + c] = v;
   }
+  __syncthreads();
+  f32x4* out = reinterpret_cast<f32x4*>(d.wp);
+  for (int e = tid; e < d.ntaps * 64; e += blockDim.x) {
+    const int t = e >> 6, lane = e & 63;
+    const int col = lane & 31, hh = lane >> 5, k = d.tapidx[t];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cil = 2 * j + hh;
+      float v = d.src_out_major ? lds[col * rstride + cil * KHW + k] : lds[cil * rstride + col * KHW + k];
+      const bool valid = (co0 + col < d.Co) && (ci0 + cil < d.Ci);
+      o[j] = valid ? v : 0.0f;   // padded rows / channels are exact zeros (also under the nonneg transform)
+    }
+    out[((long long)(chunk * d.ntaps + t) * d.ncot + cot) * 64 + lane] = o;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc d) {
+  __shared__ float lds[ICM_PACK_LDS];
+  const int units = d.ncot * d.nchunks;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) pack_unit(d, u % d.ncot, u / d.ncot, lds);
 }
 
 #define ICM_PACK_NB 24
 struct PackMulti {
   PackDesc g[ICM_PACK_NB];
 };
-__global__ void pack_weights_multi_kernel(const PackMulti m) {
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackMulti m) {
+  __shared__ float lds[ICM_PACK_LDS];
   const PackDesc& d = m.g[blockIdx.y];
-  const long long total = (long long)d.nchunks * d.ntaps * d.ncot * 256;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
-    long long q = i >> 8;
-    const int cot = (int)(q % d.ncot);
-    q /= d.ncot;
-    const int t = (int)(q % d.ntaps);
-    const int chunk = (int)(q / d.ntaps);
-    const int co = cot * 32 + (lane & 31), ci = chunk * 8 + 2 * j + (lane >> 5);
-    float v = 0.0f;
-    if (co < d.Co && ci < d.Ci) {
-      const long long src = d.src_out_major ? ((long long)co * d.Ci + ci) : ((long long)ci * d.Co + co);
-      v = d.w[src * d.KHW + d.tapidx[t]];
-      if (d.nonneg) {
-        v = fmaxf(v, d.bound);
-        v = v * v - d.pedestal;
-      }
-    }
-    d.wp[i] = v;
-  }
+  const int units = d.ncot * d.nchunks;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) pack_unit(d, u % d.ncot, u / d.ncot, lds);
 }
 
 // ---------------------------------------------------------------------------------- host planning
@@ -598,9 +607,12 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   const int ntaps = (int)cls.taps.size();
   if (ntaps > ICM_MAX_TAPS) return ICM_ERR_UNSUPPORTED;
 
-  // pick the tile configuration: time ~ ceil(workgroups / 256 CUs) x (MFMAs per MFMA wave) / efficiency, with the
-  // per-configuration efficiency measured on MI355X (tools/tune_conv.py; profiles/r01_tune_conv.txt)
-  static const double kEff[] = {0.75, 1.00, 0.80, 0.60, 1.00, 0.65, 0.80, 0.80, 0.75, 0.70};
+  // pick the tile configuration: time ~ rounds x (co-resident workgroups share the MFMA pipes: occ x MFMAs per wave /
+  // efficiency + one fixed prologue/epilogue overhead per round), rounds = ceil(workgroups / (256 CUs x occ)); occ = 2
+  // for the configurations whose kernels fit 128 VGPRs (launch bounds above), efficiencies measured on MI355X
+  // (tools/tune_conv.py; profiles/r01_tune_conv_v7.txt)
+  static const double kEff[] = {0.75, 1.00, 0.80, 0.60, 1.10, 0.65, 0.80, 0.80, 0.75, 0.70};
+  static const int kOcc[] = {1, 1, 1, 2, 2, 1, 2, 2, 2, 2};
   int best = -1;
   double best_cost = 1e300;
   Geometry bg{};
@@ -613,9 +625,10 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     if (g.lds_bytes > 160 * 1024) continue;
     if ((1 << g.lgTI) * g.PH * g.PW > ICM_MAXJ * 64) continue;   // PlaneMap capacity
     const long long blocks = (long long)cdiv(ncot, bco_t) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
-    const double per_cu = (double)((blocks + 255) / 256);
+    const int occ = (g.lds_bytes * 2 <= 160 * 1024) ? kOcc[i] : 1;
+    const double rounds = (double)((blocks + 256 * occ - 1) / (256 * occ));
     const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4;   // per MFMA wave
-    const double cost = per_cu * mfma / kEff[i] + per_cu * 200.0;
+    const double cost = rounds * (occ * mfma / kEff[i] + 200.0);
     if (cost < best_cost) {
       best_cost = cost;
       best = i;
@@ -775,7 +788,7 @@ int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int K
     for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
     for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
     const long long total = (long long)nchunks * ntaps * ncot * 256;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    const int blocks = std::min(nchunks * ncot, 2048);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
     ICM_CHECK_LAUNCH();
     off += total;
@@ -792,7 +805,7 @@ int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
   auto flush = [&]() -> int {
     if (nb == 0) return ICM_OK;
     for (int i = nb; i < ICM_PACK_NB; ++i) m.g[i] = m.g[0];
-    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(48, nb), dim3(256), 0, (hipStream_t)stream, m);
+    hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(128, nb), dim3(256), 0, (hipStream_t)stream, m);
     ICM_CHECK_LAUNCH();
     nb = 0;
     return ICM_OK;

@@ -59,6 +59,9 @@ class Tape:
         self._ws: Optional[torch.Tensor] = None
         self.wjobs: list = []
         self.pack_log = None      # when a list: records (w, args) of every cache miss (the trainer's packing plan)
+        self.pack_seq = None      # recorded miss sequence of an identical earlier step (windowed batch packing)
+        self._seq_pos = None
+        self.pack_window = 24
         self.side = None          # optional torch.cuda.Stream for deferred wgrads (overlaps the serial dgrad chain)
         self._side_ws: Optional[torch.Tensor] = None
         self._flushed: list = []  # keeps side-stream operands alive until the streams are joined
@@ -118,36 +121,49 @@ class Tape:
             self._ws = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
         return self._ws
 
-    def prepack(self, plan, store):
-        """Issue every packing job of a recorded plan (list of (w, args)) as batched launches into persistent
-        buffers ``store`` and seed the cache, so the per-layer pack() calls of this step are all hits."""
-        if not plan:
-            return
-        jobs = (L.PackJob * len(plan))()
-        for j, (w, a) in zip(jobs, plan):
-            M, K, KH, KW, som, tr, stride, pad, nonneg, bound, ped = a
-            key = (w.data_ptr(), w._version, M, K, KH, KW, som, tr, stride, pad, nonneg)
-            wp = store.get(key)
-            if wp is None:
-                wp = torch.empty(L.lib().icm_packed_weight_floats(M, K, KH, KW), dtype=torch.float32, device=w.device)
-                store[key] = wp
-            j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w), ptr(wp), M, K, KH, KW
-            j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal = som, tr, stride, pad, nonneg, bound, ped
-            self._packed[key] = wp
-        check(L.lib().icm_pack_weights_batch(jobs, len(plan), self.st), "pack_weights_batch")
-
     def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0):
-        k = (w.data_ptr(), w._version, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg)
+        """MFMA-fragment-order copy of a weight for this step.  With ``pack_seq`` (the miss sequence recorded on an
+        earlier, identical step) a miss packs a short WINDOW of upcoming weights in one launch: the ~830 tiny
+        per-layer pack launches of a training step become ~40, while every packed weight is still produced just
+        before its consumer (packing everything up front pushes it out of the Infinity Cache: DESIGN.md 5)."""
+        args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg)
+        k = (w.data_ptr(), w._version) + args
         wp = self._packed.get(k)
-        if wp is None and self.pack_log is not None:
-            self.pack_log.append((w, (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg, bound, ped)))
-        if wp is None:
-            n = L.lib().icm_packed_weight_floats(M, K, KH, KW)
-            wp = torch.empty(n, dtype=torch.float32, device=w.device)
-            check(L.lib().icm_pack_weights(ptr(w), ptr(wp), M, K, KH, KW, src_out_major, transposed, stride, pad,
-                                           nonneg, bound, ped, self.st), "pack_weights")
-            self._packed[k] = wp
+        if wp is not None:
+            return wp
+        if self.pack_log is not None:
+            self.pack_log.append((w, args + (bound, ped)))
+        lib = L.lib()
+        seq = self.pack_seq
+        if seq is not None:
+            i = self._seq_pos.get((w.data_ptr(),) + args) if self._seq_pos is not None else None
+            if i is not None:
+                jobs_w = []
+                for (w2, a2) in seq[i:i + self.pack_window]:
+                    k2 = (w2.data_ptr(), w2._version) + a2[:9]
+                    if k2 not in self._packed:
+                        wp2 = torch.empty(lib.icm_packed_weight_floats(a2[0], a2[1], a2[2], a2[3]), dtype=torch.float32,
+                                          device=w2.device)
+                        self._packed[k2] = wp2
+                        jobs_w.append((w2, a2, wp2))
+                jobs = (L.PackJob * len(jobs_w))()
+                for j, (w2, a2, wp2) in zip(jobs, jobs_w):
+                    j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w2), ptr(wp2), a2[0], a2[1], a2[2], a2[3]
+                    j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal = a2[4:11]
+                check(lib.icm_pack_weights_batch(jobs, len(jobs_w), self.st), "pack_weights_batch")
+                return self._packed[k]
+        wp = torch.empty(lib.icm_packed_weight_floats(M, K, KH, KW), dtype=torch.float32, device=w.device)
+        check(lib.icm_pack_weights(ptr(w), ptr(wp), M, K, KH, KW, src_out_major, transposed, stride, pad,
+                                   nonneg, bound, ped, self.st), "pack_weights")
+        self._packed[k] = wp
         return wp
+
+    def use_pack_sequence(self, seq, window: int = 24):
+        """seq: list of (w, (M, K, KH, KW, som, tr, stride, pad, nonneg, bound, ped)) in miss order (a ``pack_log``)"""
+        self.pack_seq, self.pack_window = seq, window
+        self._seq_pos = {}
+        for i, (w, a) in enumerate(seq):
+            self._seq_pos.setdefault((w.data_ptr(),) + a[:9], i)
 
 
 # ------------------------------------------------------------------------------------------------ raw launches

@@ -154,6 +154,8 @@ class Trainer:
         if self.wg_every < 0:
             self.side = None
         self._eb = None
+        self._pack_seq = None     # weight-packing miss sequence of the first step (windowed batch packing afterwards)
+        self.pack_window = int(_os.environ.get("ICM_PACK_WINDOW", "24"))
         self.is_stf = isinstance(model, SymmetricalTransFormer)
         self.lat_ch = 384 if self.is_stf else 320
 
@@ -178,6 +180,11 @@ class Trainer:
         tape.side, tape._side_ws, tape.progress_every = self.side, self._side_ws, self.wg_every
         tape.min_jobs = self.wg_min
         tape.stop(x)
+        if self.pack_window > 0:
+            if self._pack_seq is None:
+                tape.pack_log = []
+            else:
+                tape.use_pack_sequence(self._pack_seq, self.pack_window)
         # Weights are packed just in time (Tape.pack), right before the GEMM that reads them: measured on MI355X,
         # packing all 600 MB up front (icm_pack_weights_batch) is 8 % slower end to end -- the packed fragments
         # fall out of the 256 MB Infinity Cache before they are used and the MFMA waves then wait on HBM.
@@ -206,6 +213,8 @@ class Trainer:
             tape.bw.insert(idx, (lambda b=name: (E.flush_wgrads(tape), tape.join_side(), self.reducer.launch(b))))
         tape.backward()
         self._side_ws = tape._side_ws
+        if tape.pack_log is not None and self._pack_seq is None:
+            self._pack_seq = tape.pack_log
         self.reducer.launch(len(BUCKETS) - 1)   # g_a: last gradients to complete
         if len(f.bucket_ranges) > len(BUCKETS):
             self.reducer.launch(len(BUCKETS))

@@ -16,8 +16,14 @@ for p in range(200, len(sig) - first - 50):
     if sig[first + p:first + p + 50] == sig[first:first + 50]:
         period = p; break
 print("rows", len(rows), "first", first, "period", period)
-a = first + period
-b = a + period if a + period <= len(rows) else len(rows)
+marks = [i for i, n in enumerate(names) if n.startswith("sqnorm_kernel")]
+if len(marks) >= 2:   # train trace: one grad-norm kernel per step -> take the last full step (windowed packing makes step 1 differ)
+    period = marks[-1] - marks[-2]
+    a = marks[-2] + 4   # sqnorm, adam, eb_aux, adam_aux end the previous step
+    b = marks[-1] + 4
+else:
+    a = first + period
+    b = a + period if a + period <= len(rows) else len(rows)
 step = list(zip(names[a:b], rows[a:b]))
 t0, t1 = step[0][1]["s"], max(r["e"] for _, r in step)
 busy = 0; cur_end = t0; gaps = 0

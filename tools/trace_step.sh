@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for mode in fwd train; do
   extra=""; [ $mode = fwd ] && extra="--fwd-only"
   rm -rf $R/gpurun_out/trace_$mode
-  timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_$mode -- python3 $R/bench.py $extra --model ${MODEL:-cnn} --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/trace_$mode.log 2>&1 || echo "trace $mode failed"
+  timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_$mode -- python3 $R/bench.py $extra --model ${MODEL:-cnn} --steps 1 --warmup 2 --no-cpu-baseline > $R/gpurun_out/trace_$mode.log 2>&1 || echo "trace $mode failed"
   f=$(find $R/gpurun_out/trace_$mode -name '*kernel_trace.csv' | head -1)
   # keep only the columns needed, gzip to stay small
   python3 - "$f" "$R/gpurun_out/trace_${MODEL:-cnn}_$mode.csv.gz" <<'PY'
