@@ -17,6 +17,7 @@
 //   * pointwise neighbours are fused: operand activation on the LDS staging path (virtual GELU,
 //     x^2 for GDN) and the epilogues listed in icm_hip.h (bias, residual, GDN rsqrt, GELU', LRP tanh,
 //     PixelShuffle store, gradient accumulation).
+#include <cstdlib>
 #include <vector>
 #include "icm_common.h"
 
@@ -223,15 +224,14 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const f32x4* wp4 = reinterpret_cast<const f32x4*>(P.wp);
+  const char* wbase = reinterpret_cast<const char*>(P.wp);   // wave-uniform: weight loads are saddr + 32-bit voffset
   const int cot0 = cb * BCO_T + wco * TCO;
-
-  int wl[TCO];  // per-lane fragment index of co tile a at Q = 0
+  unsigned wl[TCO];  // per-lane byte offset of the fragment of co tile a inside one (chunk8, tap) step
 #pragma unroll
-  for (int a = 0; a < TCO; ++a) wl[a] = min(cot0 + a, d.ncot - 1) * 64 + lane;
-  const int qstride = d.ncot * 64;             // f32x4 elements between consecutive (chunk8, tap) steps
+  for (int a = 0; a < TCO; ++a) wl[a] = (unsigned)(min(cot0 + a, d.ncot - 1) * 64 + lane) * 16u;
+  const long long qstride = (long long)d.ncot * 64 * 16;   // bytes between consecutive (chunk8, tap) steps
   const int Qtot = d.nchunks8 * d.ntaps;
-  if constexpr (TS > 1) {
+  {
     // LDS offset of sub-step q of a chunk (8-channel group q / ntaps, tap q % ntaps) lives in lane q of one VGPR:
     // v_readlane replaces the scalar (group, tap) bookkeeping; the host guarantees ckm * ntaps <= 64
     int step_lane;
@@ -239,160 +239,87 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
       const int sq = lane / d.ntaps, tq = lane - sq * d.ntaps;
       step_lane = sq * 8 * pg.CS + d.tapoff[tq];
     }
-
-    f32x4 a_n[TS][TCO];   // weights of the next step; prefetched across chunk boundaries (they do not live in LDS)
+    // Pipeline over steps of TS (8-channel group, tap) sub-steps (small tiles take TS > 1 so that a step carries
+    // >= 8-12 MFMAs).  A fragments (packed weights) come from L2, whose latency exceeds one step of a small tile:
+    // they are prefetched TWO steps ahead into two register sets used alternately (the step loop is unrolled by two,
+    // chunks are padded to an even number of steps with zeroed B fragments).  B fragments come from LDS one step ahead.
+    auto chunk_nq = [&](int c) { return min(d.ckm, d.nchunks8 - c * d.ckm) * d.ntaps; };
+    // scalar pointer to the packed weights of sub-step u of step `st` of chunk `c` (st may run past the chunk:
+    // first steps of the next chunk; past the end: clamped, never used)
+    auto wptr = [&](int c, int st, int u) -> const char* {
+      int nq_c = chunk_nq(c);
+      const int ns2 = (((nq_c + TS - 1) / TS) + 1) & ~1;
+      if (st >= ns2) {
+        st -= ns2;
+        c += 1;
+        nq_c = (c < nchunks) ? chunk_nq(c) : 1;
+      }
+      const int qw = min(c * d.ckm * d.ntaps + min(st * TS + u, nq_c - 1), Qtot - 1);
+      return wbase + qw * qstride;
+    };
+    f32x4 aq0[TS][TCO], aq1[TS][TCO];
 #pragma unroll
     for (int u = 0; u < TS; ++u)
 #pragma unroll
-      for (int a = 0; a < TCO; ++a) a_n[u][a] = wp4[(long long)min(u, Qtot - 1) * qstride + wl[a]];
+      for (int a = 0; a < TCO; ++a) {
+        aq0[u][a] = *reinterpret_cast<const f32x4*>(wptr(0, 0, u) + wl[a]);
+        aq1[u][a] = *reinterpret_cast<const f32x4*>(wptr(0, 1, u) + wl[a]);
+      }
 
     __syncthreads();  // patch of chunk 0 staged
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const float* cur = smem + (chunk & 1) * bufsz;
-      const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
-      const int nq = nsub * d.ntaps;
-      const int Qbase = chunk * d.ckm * d.ntaps;
-      const int nsteps = (nq + TS - 1) / TS;
-      // Software pipeline over steps of TS (8-channel group, tap) sub-steps, branch-free so that a step is one
-      // basic block: the fragments of step s+1 (B from LDS, A = packed weights from L2) are fetched in the
-      // shadows of step s's MFMAs.  Small tiles take TS > 1 so that a step carries >= 8-12 MFMAs: the wave issues
-      // in order, and whatever trails the last MFMA of a step runs with the matrix pipe idle.
+      const int nq = chunk_nq(chunk);
+      const int nsteps2 = (((nq + TS - 1) / TS) + 1) & ~1;
       float bv_n[TS][4][TPX];
-#pragma unroll
-      for (int u = 0; u < TS; ++u) {
-        const int qc = min(u, nq - 1);
-        const float okf = (u < nq) ? 1.0f : 0.0f;
+      float ok_n[TS];   // 1 / 0 (wave-uniform): sub-steps past the chunk contribute zero; applied when bv_n is consumed
+      // B fragments of sub-step u of step st of this chunk into bv_n
+      auto bload = [&](int st, int u) {
+        const int qq = st * TS + u;
+        const int qc = min(qq, nq - 1);
+        ok_n[u] = (qq < nq) ? 1.0f : 0.0f;
         const float* bp = cur + __builtin_amdgcn_readlane(step_lane, qc);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int tp = 0; tp < TPX; ++tp) bv_n[u][j][tp] = bp[boff[tp] + 2 * j * pg.CS] * okf;
-      }
-      for (int st = 0; st < nsteps; ++st) {
-        f32x4 a_c[TS][TCO];
+          for (int tp = 0; tp < TPX; ++tp) bv_n[u][j][tp] = bp[boff[tp] + 2 * j * pg.CS];
+      };
+      // One step with register set `aq`.  Source order IS the issue order (sched_barrier pins each group): the four
+      // k-pairs of a weight fragment issue back to back, then -- while the matrix pipe works them off -- the LDS
+      // reads of the next step's B fragments and the refill of this fragment with the weights two steps ahead.
+      auto half_step = [&](f32x4 (&aq)[TS][TCO], int st) {
         float bv[TS][4][TPX];
-#pragma unroll
-        for (int u = 0; u < TS; ++u) {
-#pragma unroll
-          for (int a = 0; a < TCO; ++a) a_c[u][a] = a_n[u][a];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tp = 0; tp < TPX; ++tp) bv[u][j][tp] = bv_n[u][j][tp];
-        }
-        const int sn = min(st + 1, nsteps - 1);
-#pragma unroll
-        for (int u = 0; u < TS; ++u) {
-          const int qq = sn * TS + u;
-          const int qc = min(qq, nq - 1);
-          const float* bp = cur + __builtin_amdgcn_readlane(step_lane, qc);
-          const float okf = (qq < nq) ? 1.0f : 0.0f;   // sub-steps past the chunk contribute zero
-          // last step of the chunk: fetch the first step of the NEXT chunk instead (Q is contiguous across chunks)
-          const int qw = (st + 1 < nsteps) ? Qbase + qc : min(Qbase + nq + u, Qtot - 1);
-#pragma unroll
-          for (int a = 0; a < TCO; ++a) a_n[u][a] = wp4[(long long)qw * qstride + wl[a]];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tp = 0; tp < TPX; ++tp) {
-              const float v = bp[boff[tp] + 2 * j * pg.CS];
-              bv_n[u][j][tp] = (TS == 1) ? v : v * okf;
-            }
-        }
 #pragma unroll
         for (int u = 0; u < TS; ++u)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int a = 0; a < TCO; ++a)
+            for (int tp = 0; tp < TPX; ++tp) bv[u][j][tp] = bv_n[u][j][tp] * ok_n[u];
+        const int stn = min(st + 1, nsteps2 - 1);
 #pragma unroll
-              for (int tp = 0; tp < TPX; ++tp)
-                acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[u][a][j], bv[u][j][tp], acc[a][tp], 0, 0, 0);
-        // issue order: after each MFMA (64 cycles of matrix pipe) slot in one fragment fetch of the NEXT step
+        for (int u = 0; u < TS; ++u) {
+          const char* sp = wptr(chunk, st + 2, u);
 #pragma unroll
-        for (int m = 0; m < TS * 4 * TCO * TPX; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (m < TS * TCO) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          if (m < TS * 4 * TPX) {
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-        }
-      }
-      __syncthreads();
-    }
-
-  } else {
-    int Q = 0;
-    f32x4 a_nxt[TCO];
-#pragma unroll
-    for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[wl[a]];
-
-    const int toff_lane = d.tapoff[lane & 31];   // tap offsets live in one VGPR; v_readlane picks entry t
-    __syncthreads();  // patch of chunk 0 staged
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      const float* cur = smem + (chunk & 1) * bufsz;
-      const int nsub = min(d.ckm, d.nchunks8 - chunk * d.ckm);
-      const int nq = nsub * d.ntaps;
-      // software pipeline over (8-channel group, tap) steps, branch-free so that each step is one basic block:
-      // B fragments of step q+1 are read from LDS and A fragments (weights) of step Q+1 from L2 while the MFMAs of
-      // step q issue; the last step of a chunk re-reads its own fragments
-      float bv_n[4][TPX];
-      {
-        const float* bp = cur + __builtin_amdgcn_readlane(toff_lane, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
-      }
-      int sub = 0, t = 0;
-      for (int q = 0; q < nq; ++q) {
-        f32x4 a_cur[TCO];
-        float bv[4][TPX];
-#pragma unroll
-        for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int tp = 0; tp < TPX; ++tp) bv[j][tp] = bv_n[j][tp];
-        Q = min(Q + 1, Qtot - 1);
-#pragma unroll
-        for (int a = 0; a < TCO; ++a) a_nxt[a] = wp4[(long long)Q * qstride + wl[a]];
-        {
-          const bool last = q + 1 == nq;
-          int tn = t + 1, subn = sub;
-          const bool wrap = tn == d.ntaps;
-          tn = wrap ? 0 : tn;
-          subn = wrap ? sub + 1 : sub;
-          t = last ? t : tn;
-          sub = last ? sub : subn;
-          const float* bp = cur + sub * 8 * pg.CS + __builtin_amdgcn_readlane(toff_lane, t);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tp = 0; tp < TPX; ++tp) bv_n[j][tp] = bp[boff[tp] + 2 * j * pg.CS];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int a = 0; a < TCO; ++a)
+          for (int a = 0; a < TCO; ++a) {
 #pragma unroll
             for (int tp = 0; tp < TPX; ++tp)
-              acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][j], bv[j][tp], acc[a][tp], 0, 0, 0);
-        // issue order: after each MFMA (64 cycles of matrix pipe) slot in one fragment fetch of the NEXT step
 #pragma unroll
-        for (int m = 0; m < 4 * TCO * TPX; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (m < TCO) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-          if (m < 4 * TPX) {
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              for (int j = 0; j < 4; ++j)
+                acc[a][tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][a][j], bv[u][j][tp], acc[a][tp], 0, 0, 0);
+            if (a == 0) bload(stn, u);
+            aq[u][a] = *reinterpret_cast<const f32x4*>(sp + wl[a]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+      };
+#pragma unroll
+      for (int u = 0; u < TS; ++u) bload(0, u);
+      for (int st = 0; st < nsteps2; st += 2) {
+        half_step(aq0, st);
+        half_step(aq1, st + 1);
       }
       __syncthreads();
     }
-
   }
 
   // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h.  The epilogue kind is
@@ -590,7 +517,7 @@ static Geometry make_geometry(int bpx, int OHv, int OWv, int N, int S, int ey, i
   // round trips and the barrier itself stay hidden, within 64 KB of LDS for the two buffers
   int ckm = cdiv(256, ntaps * 4 * tiles_per_wave);
   ckm = std::max(1, std::min(ckm, nchunks8));
-  if (tiles_per_wave <= 2) ckm = std::max(1, std::min(ckm, 64 / std::max(1, ntaps)));   // step table = one VGPR
+  ckm = std::max(1, std::min(ckm, 64 / std::max(1, ntaps)));   // step table = one VGPR (64 lanes)
   while (ckm > 1 && (size_t)2 * ckm * 8 * g.CS * sizeof(float) > 64 * 1024) --ckm;
   g.ckm = ckm;
   g.lds_bytes = (size_t)2 * ckm * 8 * g.CS * sizeof(float);
@@ -613,6 +540,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   // (tools/tune_conv.py; profiles/r01_tune_conv_v7.txt)
   static const double kEff[] = {0.75, 1.00, 0.80, 0.60, 1.10, 0.65, 0.80, 0.80, 0.75, 0.70};
   static const int kOcc[] = {1, 1, 1, 2, 2, 1, 2, 2, 2, 2};
+  static const double kCoResBoost = getenv("ICM_CONV_BOOST") ? atof(getenv("ICM_CONV_BOOST")) : 1.25;
   int best = -1;
   double best_cost = 1e300;
   Geometry bg{};
@@ -625,10 +553,12 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     if (g.lds_bytes > 160 * 1024) continue;
     if ((1 << g.lgTI) * g.PH * g.PW > ICM_MAXJ * 64) continue;   // PlaneMap capacity
     const long long blocks = (long long)cdiv(ncot, bco_t) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
-    const int occ = (g.lds_bytes * 2 <= 160 * 1024) ? kOcc[i] : 1;
+    const int occ_max = (g.lds_bytes * 2 <= 160 * 1024) ? kOcc[i] : 1;
+    const int occ = (int)std::min<long long>(occ_max, (blocks + 255) / 256);   // workgroups actually co-resident
     const double rounds = (double)((blocks + 256 * occ - 1) / (256 * occ));
     const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4;   // per MFMA wave
-    const double cost = rounds * (occ * mfma / kEff[i] + 200.0);
+    // two co-resident workgroups interleave their MFMA streams: the issue gaps of one wave per SIMD are filled
+    const double cost = rounds * (occ * mfma / (kEff[i] * (occ > 1 ? kCoResBoost : 1.0)) + 200.0);
     if (cost < best_cost) {
       best_cost = cost;
       best = i;
