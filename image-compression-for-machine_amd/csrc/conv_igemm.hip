@@ -148,10 +148,12 @@ __device__ __forceinline__ void epilogue_all(const ConvDesc& d, const ConvPtrs& 
 // waves 4-7 are loaders that stage the NEXT K-chunk's halo patch into the other LDS buffer meanwhile.
 // MFMA and VALU/VMEM are separate pipes per SIMD, so with one MFMA wave and one loader wave per SIMD the
 // staging cost disappears behind the 64-cycle v_mfma_f32_32x32x2_f32 issue interval.
-template <int WCO, int WPX, int TCO, int TPX>
+// KS > 1: intra-workgroup split-K for small problems (few output tiles, deep K): KS MFMA waves share one output
+// tile, each taking every KS-th (8-channel group, tap) sub-step; partial accumulators are summed through LDS.
+template <int WCO, int WPX, int TCO, int TPX, int KS = 1>
 __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  static_assert(WCO * WPX == 4, "4 MFMA waves per workgroup");
+  static_assert(WCO * WPX * KS == 4, "4 MFMA waves per workgroup");
   constexpr int BCO_T = WCO * TCO;
   // small tiles: pipeline steps of TS (8-channel group, tap) sub-steps so that a step carries >= 8-12 MFMAs
   constexpr int TS = (TCO * TPX == 1) ? 3 : ((TCO * TPX == 2) ? 2 : 1);
@@ -205,7 +207,8 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
   }
 
   // ------------------------------------------------------------------ MFMA waves
-  const int wco = wave / WPX, wpx = wave % WPX;
+  const int wk = wave % KS, wsp = wave / KS;   // K-split index, spatial wave index
+  const int wco = wsp / WPX, wpx = wsp % WPX;
   const int h = lane >> 5, l31 = lane & 31;
   const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
   const int rowmul = S_in * pg.PWrow;
@@ -246,15 +249,17 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
     auto chunk_nq = [&](int c) { return min(d.ckm, d.nchunks8 - c * d.ckm) * d.ntaps; };
     // scalar pointer to the packed weights of sub-step u of step `st` of chunk `c` (st may run past the chunk:
     // first steps of the next chunk; past the end: clamped, never used)
+    // sub-steps of a chunk taken by this wave: q = wk, wk + KS, ...; padded to an even number of steps
+    auto steps2 = [&](int nq_c) { return ((((nq_c - wk + KS - 1) / KS) + TS - 1) / TS + 1) & ~1; };
     auto wptr = [&](int c, int st, int u) -> const char* {
       int nq_c = chunk_nq(c);
-      const int ns2 = (((nq_c + TS - 1) / TS) + 1) & ~1;
+      const int ns2 = steps2(nq_c);
       if (st >= ns2) {
         st -= ns2;
         c += 1;
         nq_c = (c < nchunks) ? chunk_nq(c) : 1;
       }
-      const int qw = min(c * d.ckm * d.ntaps + min(st * TS + u, nq_c - 1), Qtot - 1);
+      const int qw = min(c * d.ckm * d.ntaps + min((st * TS + u) * KS + wk, nq_c - 1), Qtot - 1);
       return wbase + qw * qstride;
     };
     f32x4 aq0[TS][TCO], aq1[TS][TCO];
@@ -270,12 +275,12 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const float* cur = smem + (chunk & 1) * bufsz;
       const int nq = chunk_nq(chunk);
-      const int nsteps2 = (((nq + TS - 1) / TS) + 1) & ~1;
+      const int nsteps2 = steps2(nq);
       float bv_n[TS][4][TPX];
       float ok_n[TS];   // 1 / 0 (wave-uniform): sub-steps past the chunk contribute zero; applied when bv_n is consumed
       // B fragments of sub-step u of step st of this chunk into bv_n
       auto bload = [&](int st, int u) {
-        const int qq = st * TS + u;
+        const int qq = (st * TS + u) * KS + wk;
         const int qc = min(qq, nq - 1);
         ok_n[u] = (qq < nq) ? 1.0f : 0.0f;
         const float* bp = cur + __builtin_amdgcn_readlane(step_lane, qc);
@@ -322,6 +327,22 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
     }
   }
 
+  if constexpr (KS > 1) {
+    // split-K reduction: the staging buffers are free after the last chunk barrier (the loaders have left: ended
+    // waves do not take part in s_barrier).  Waves wk > 0 park their accumulators in LDS, wave wk == 0 adds them.
+    static_assert(TCO == 1 && TPX == 1, "split-K configurations hold one tile per wave");
+    float* red = smem + (wsp * (KS - 1)) * 1024;
+    if (wk > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wk - 1) * 1024 + r * 64 + lane] = acc[0][0][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] += red[k * 1024 + r * 64 + lane];
+  }
   // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h.  The epilogue kind is
   // dispatched ONCE (uniform branch) around the fully unrolled tile loops.
   switch (d.epi) {
@@ -476,6 +497,7 @@ static std::vector<ConvClass> build_classes(int KH, int KW, int stride, int pad,
 struct KernelCfg {
   int wco, wpx, tco, tpx;
   void (*fn)(const ConvDesc);
+  int ks = 1;
 };
 static const KernelCfg kCfgs[] = {
     {1, 4, 3, 2, conv_igemm_kernel<1, 4, 3, 2>},  // 96 co x 256 px
@@ -488,6 +510,9 @@ static const KernelCfg kCfgs[] = {
     {2, 2, 1, 1, conv_igemm_kernel<2, 2, 1, 1>},  // 64 x 64
     {4, 1, 1, 1, conv_igemm_kernel<4, 1, 1, 1>},  // 128 x 32
     {1, 4, 1, 1, conv_igemm_kernel<1, 4, 1, 1>},  // 32 x 128
+    {2, 1, 1, 1, conv_igemm_kernel<2, 1, 1, 1, 2>, 2},  // 64 x 32, K split in 2
+    {1, 2, 1, 1, conv_igemm_kernel<1, 2, 1, 1, 2>, 2},  // 32 x 64, K split in 2
+    {1, 1, 1, 1, conv_igemm_kernel<1, 1, 1, 1, 4>, 4},  // 32 x 32, K split in 4
 };
 static int g_force_cfg = -1;
 
@@ -538,8 +563,8 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   // efficiency + one fixed prologue/epilogue overhead per round), rounds = ceil(workgroups / (256 CUs x occ)); occ = 2
   // for the configurations whose kernels fit 128 VGPRs (launch bounds above), efficiencies measured on MI355X
   // (tools/tune_conv.py; profiles/r01_tune_conv_v7.txt)
-  static const double kEff[] = {0.75, 1.00, 0.80, 0.60, 1.10, 0.65, 0.80, 0.80, 0.75, 0.70};
-  static const int kOcc[] = {1, 1, 1, 2, 2, 1, 2, 2, 2, 2};
+  static const double kEff[] = {0.75, 1.00, 0.80, 0.60, 1.10, 0.65, 0.80, 0.80, 0.75, 0.70, 0.70, 0.70, 0.65};
+  static const int kOcc[] = {1, 1, 1, 2, 2, 1, 2, 2, 2, 2, 2, 2, 2};
   static const double kCoResBoost = getenv("ICM_CONV_BOOST") ? atof(getenv("ICM_CONV_BOOST")) : 1.25;
   int best = -1;
   double best_cost = 1e300;
@@ -550,13 +575,14 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     const KernelCfg& c = kCfgs[i];
     const int bpx = c.wpx * c.tpx * 32, bco_t = c.wco * c.tco;
     Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps, c.tco * c.tpx);
+    if (c.ks > 1) g.lds_bytes = std::max<size_t>(g.lds_bytes, (size_t)(c.ks - 1) * c.wco * c.wpx * 4096);
     if (g.lds_bytes > 160 * 1024) continue;
     if ((1 << g.lgTI) * g.PH * g.PW > ICM_MAXJ * 64) continue;   // PlaneMap capacity
     const long long blocks = (long long)cdiv(ncot, bco_t) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
     const int occ_max = (g.lds_bytes * 2 <= 160 * 1024) ? kOcc[i] : 1;
     const int occ = (int)std::min<long long>(occ_max, (blocks + 255) / 256);   // workgroups actually co-resident
     const double rounds = (double)((blocks + 256 * occ - 1) / (256 * occ));
-    const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4;   // per MFMA wave
+    const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4 / c.ks + (c.ks > 1 ? 24.0 : 0.0);   // per MFMA wave
     // two co-resident workgroups interleave their MFMA streams: the issue gaps of one wave per SIMD are filled
     const double cost = rounds * (occ * mfma / (kEff[i] * (occ > 1 ? kCoResBoost : 1.0)) + 200.0);
     if (cost < best_cost) {

@@ -111,11 +111,27 @@ def test_conv_every_tile_config():
         m.weight.copy_(w)
         m.bias.copy_(b)
     try:
-        for cfg in range(8):
+        for cfg in range(13):   # 10 tile shapes + 3 intra-workgroup split-K variants
             lib.icm_debug_force_conv_cfg(cfg)
             with torch.no_grad():
                 y = m(x.to(d))
             close(y, yr, what=f"cfg{cfg}")
+        # 1x1 and stride-2 5x5 through the split-K variants as well (odd channel counts: K tails per split differ)
+        for (ci, co, k, s_) in ((13, 70, 1, 1), (21, 33, 5, 2), (8, 32, 3, 1)):
+            m2 = layers.Conv2d(ci, co, kernel_size=k, stride=s_, padding=k // 2)
+            w2 = U(f"cfg2.w{ci}", m2.weight.shape, -0.2, 0.2)
+            b2 = U(f"cfg2.b{ci}", m2.bias.shape, -0.5, 0.5)
+            x2 = U(f"cfg2.x{ci}", (2, ci, 18, 24), -1.0, 1.0)
+            yr2 = F.conv2d(x2, w2, b2, stride=s_, padding=k // 2)
+            m2 = m2.to(d)
+            with torch.no_grad():
+                m2.weight.copy_(w2)
+                m2.bias.copy_(b2)
+            for cfg in (7, 10, 11, 12):
+                lib.icm_debug_force_conv_cfg(cfg)
+                with torch.no_grad():
+                    y2 = m2(x2.to(d))
+                close(y2, yr2, what=f"cfg{cfg} {ci}->{co} k{k}")
     finally:
         lib.icm_debug_force_conv_cfg(-1)
 

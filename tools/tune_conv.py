@@ -14,7 +14,7 @@ lib = _lib.lib()
 lib.icm_debug_force_conv_cfg.argtypes = [ctypes.c_int]
 lib.icm_debug_force_conv_cfg.restype = None
 dev = torch.device("cuda:0")
-NCFG = 10
+NCFG = 13
 
 # name, N, Cin, H, W, Cout, k, stride, transposed
 SHAPES = [
