@@ -207,7 +207,8 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
   }
 
   // ------------------------------------------------------------------ MFMA waves
-  const int wk = wave % KS, wsp = wave / KS;   // K-split index, spatial wave index
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // wave-uniform: step bookkeeping stays on the scalar unit
+  const int wk = wave_u % KS, wsp = wave_u / KS;   // K-split index, spatial wave index
   const int wco = wsp / WPX, wpx = wsp % WPX;
   const int h = lane >> 5, l31 = lane & 31;
   const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
