@@ -585,7 +585,10 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     const double rounds = (double)((blocks + 256 * occ - 1) / (256 * occ));
     const double mfma = (double)c.tco * c.tpx * nchunks8 * ntaps * 4 / c.ks + (c.ks > 1 ? 24.0 : 0.0);   // per MFMA wave
     // two co-resident workgroups interleave their MFMA streams: the issue gaps of one wave per SIMD are filled
-    const double cost = rounds * (occ * mfma / (kEff[i] * (occ > 1 ? kCoResBoost : 1.0)) + 200.0);
+    double cost = rounds * (occ * mfma / (kEff[i] * (occ > 1 ? kCoResBoost : 1.0)) + 200.0);
+    // every extra co-block re-stages the whole halo patch from L2 / HBM: for halo convolutions with many pixels a
+    // few percent of MFMA time is traded for one pass over the activations (measured: 1.85x FETCH_SIZE otherwise)
+    if (ntaps >= 9 && (long long)OHv * OWv * a.N >= 16384) cost *= 1.0 + 0.06 * (cdiv(ncot, bco_t) - 1);
     if (cost < best_cost) {
       best_cost = cost;
       best = i;
