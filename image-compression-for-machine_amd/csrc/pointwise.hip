@@ -148,68 +148,101 @@ __global__ void pixel_unshuffle2_kernel(const float* src, float* dst, int N, int
   }
 }
 // ---------------------------------------------------------------- LayerNorm over channels on NCHW (stf.py: nn.LayerNorm(C) on tokens)
-// thread = pixel; channel loop strides by HW so every load/store is coalesced across the wave
-__global__ void layernorm_fwd_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, float* __restrict__ y, long long ybs,
-                                     float* __restrict__ mean, float* __restrict__ rstd, int N, int C, int HW,
-                                     float eps) {
+// workgroup = 64 pixels x 4 channel slices: lane = pixel (every load/store of a wave is one 256-B row of a channel
+// plane), wave = channel slice c = w, w+4, ...; the per-pixel channel sums of the four slices meet in LDS.
+// Two-pass statistics (mean, then centred variance) like the reference's nn.LayerNorm.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long long xbs,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            long long ybs, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int N, int C, int HW, float eps) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long total = (long long)N * HW;
-  GRID_STRIDE(i, total) {
-    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+  const long long ntiles = (total + 63) / 64;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long i = tile * 64 + lane;
+    const bool valid = i < total;
+    const int n = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (long long)n * HW) : 0;
     const float* xp = x + n * xbs + p;
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += xp[(long long)c * HW];
-    const float m = s / (float)C;
+    if (valid)
+      for (int c = cs; c < C; c += 4) s += xp[(long long)c * HW];
+    red[cs][lane] = s;
+    __syncthreads();
+    const float m = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)C;
+    __syncthreads();
     float v = 0.0f;
-    for (int c = 0; c < C; ++c) {
-      const float d = xp[(long long)c * HW] - m;
-      v += d * d;
+    if (valid)
+      for (int c = cs; c < C; c += 4) {
+        const float d = xp[(long long)c * HW] - m;
+        v += d * d;
+      }
+    red[cs][lane] = v;
+    __syncthreads();
+    const float r = rsqrtf(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)C + eps);
+    __syncthreads();
+    if (valid) {
+      if (cs == 0 && mean) { mean[i] = m; rstd[i] = r; }
+      float* yp = y + n * ybs + p;
+      for (int c = cs; c < C; c += 4) yp[(long long)c * HW] = (xp[(long long)c * HW] - m) * r * gamma[c] + beta[c];
     }
-    const float r = rsqrtf(v / (float)C + eps);
-    if (mean) { mean[i] = m; rstd[i] = r; }
-    float* yp = y + n * ybs + p;
-    for (int c = 0; c < C; ++c) yp[(long long)c * HW] = (xp[(long long)c * HW] - m) * r * gamma[c] + beta[c];
   }
 }
 // dx = rstd * (g*gamma - mean_c(g*gamma) - xhat * mean_c(g*gamma*xhat))
-__global__ void layernorm_bwd_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ dy,
-                                     long long dbs, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                     const float* __restrict__ rstd, float* __restrict__ dx, long long dxbs, int N,
-                                     int C, int HW, int accum) {
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, long long xbs,
+                                                            const float* __restrict__ dy, long long dbs,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            long long dxbs, int N, int C, int HW, int accum) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long total = (long long)N * HW;
-  GRID_STRIDE(i, total) {
-    const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
+  const long long ntiles = (total + 63) / 64;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long i = tile * 64 + lane;
+    const bool valid = i < total;
+    const int n = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (long long)n * HW) : 0;
     const float* xp = x + n * xbs + p;
     const float* gp = dy + n * dbs + p;
-    const float m = mean[i], r = rstd[i];
+    const float m = valid ? mean[i] : 0.0f, r = valid ? rstd[i] : 0.0f;
     float s1 = 0.0f, s2 = 0.0f;
-    for (int c = 0; c < C; ++c) {
-      const float gg = gp[(long long)c * HW] * gamma[c];
-      s1 += gg;
-      s2 += gg * (xp[(long long)c * HW] - m) * r;
-    }
-    s1 /= (float)C;
-    s2 /= (float)C;
-    float* dp = dx + n * dxbs + p;
-    for (int c = 0; c < C; ++c) {
-      const float xh = (xp[(long long)c * HW] - m) * r;
-      float v = r * (gp[(long long)c * HW] * gamma[c] - s1 - xh * s2);
-      if (accum) v += dp[(long long)c * HW];
-      dp[(long long)c * HW] = v;
+    if (valid)
+      for (int c = cs; c < C; c += 4) {
+        const float gg = gp[(long long)c * HW] * gamma[c];
+        s1 += gg;
+        s2 += gg * (xp[(long long)c * HW] - m) * r;
+      }
+    red[0][cs][lane] = s1;
+    red[1][cs][lane] = s2;
+    __syncthreads();
+    s1 = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
+    s2 = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
+    __syncthreads();
+    if (valid) {
+      float* dp = dx + n * dxbs + p;
+      for (int c = cs; c < C; c += 4) {
+        const float xh = (xp[(long long)c * HW] - m) * r;
+        float v = r * (gp[(long long)c * HW] * gamma[c] - s1 - xh * s2);
+        if (accum) v += dp[(long long)c * HW];
+        dp[(long long)c * HW] = v;
+      }
     }
   }
 }
-// dgamma[c] = sum_{n,p} dy * xhat ; dbeta[c] = sum dy   (one workgroup per channel)
+// dgamma[c] += sum_{n,p} dy * xhat ; dbeta[c] += sum dy.  grid (C, S): workgroup (c, s) reduces pixel chunk s of
+// channel c and adds its partial with one float atomic per output (outputs zeroed first unless accumulating)
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, long long xbs,
                                                                    const float* __restrict__ dy, long long dbs,
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, float* dgamma,
-                                                                   float* dbeta, int N, int C, int HW, int accum) {
+                                                                   float* dbeta, int N, int C, int HW) {
   __shared__ float red[2][4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, S = gridDim.y, sp = blockIdx.y;
   float sg = 0.0f, sb = 0.0f;
   const long long total = (long long)N * HW;
-  for (long long i = threadIdx.x; i < total; i += 256) {
+  for (long long i = (long long)sp * 256 + threadIdx.x; i < total; i += (long long)S * 256) {
     const int n = (int)(i / HW), p = (int)(i - (long long)n * HW);
     const float g = dy[n * dbs + (long long)c * HW + p];
     const float xh = (x[n * xbs + (long long)c * HW + p] - mean[i]) * rstd[i];
@@ -221,11 +254,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sb; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    float b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    if (accum) { a += dgamma[c]; b += dbeta[c]; }
-    dgamma[c] = a;
-    dbeta[c] = b;
+    atomicAdd(dgamma + c, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    atomicAdd(dbeta + c, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
   }
 }
 // PatchMerging gather (stf.py:224-228): dst[n][k*C + c][y][x] = src[n][c][2y + (k&1)][2x + (k>>1)]; inverse = its gradient
@@ -432,8 +462,9 @@ int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int 
 int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const float* beta, float* y, int64_t y_bs,
                       float* mean, float* rstd, int N, int C, int HW, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for((long long)N * HW, 1)), dim3(256), 0, ST, x, (long long)x_bs,
-                     gamma, beta, y, (long long)y_bs, mean, rstd, N, C, HW, eps);
+  const long long tiles = ((long long)N * HW + 63) / 64;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)std::min<long long>(tiles, 256 * 16)), dim3(256), 0, ST, x,
+                     (long long)x_bs, gamma, beta, y, (long long)y_bs, mean, rstd, N, C, HW, eps);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
@@ -442,13 +473,21 @@ int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
                       int N, int C, int HW, int accum_dx, int accum_params, void* stream) {
   if (!x || !dy || !gamma || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   if (dx) {
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid_for((long long)N * HW, 1)), dim3(256), 0, ST, x, (long long)x_bs,
-                       dy, (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx);
+    const long long tiles = ((long long)N * HW + 63) / 64;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)std::min<long long>(tiles, 256 * 16)), dim3(256), 0, ST, x,
+                       (long long)x_bs, dy, (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx);
     ICM_CHECK_LAUNCH();
   }
   if (dgamma && dbeta) {
-    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(C), dim3(256), 0, ST, x, (long long)x_bs, dy, (long long)dy_bs,
-                       mean, rstd, dgamma, dbeta, N, C, HW, accum_params);
+    if (!accum_params) {
+      if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, ST) != hipSuccess) return ICM_ERR_LAUNCH;
+      if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, ST) != hipSuccess) return ICM_ERR_LAUNCH;
+    }
+    // enough pixel chunks to fill the chip whatever C is (C = 48 at the 128x128 level)
+    const long long chunks = ((long long)N * HW + 4095) / 4096;
+    const int S = (int)std::max<long long>(1, std::min<long long>(chunks, (2048 + C - 1) / C));
+    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(C, S), dim3(256), 0, ST, x, (long long)x_bs, dy,
+                       (long long)dy_bs, mean, rstd, dgamma, dbeta, N, C, HW);
     ICM_CHECK_LAUNCH();
   }
   return ICM_OK;

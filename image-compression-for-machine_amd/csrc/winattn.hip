@@ -24,7 +24,7 @@ struct WaDesc {
   const float* dout;   // bwd
   float* dqkv;         // bwd
   float* dtable;       // bwd
-  int N, C, H, W, heads, ws, shift, hd, T, nwx, nwy;
+  int N, C, H, W, heads, ws, shift, hd, T, nwx, nwy, G;
   float scale;
 };
 
@@ -93,9 +93,11 @@ __device__ __forceinline__ void axpy_row(float (&o)[HD], float p, const float* _
 template <int HD>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int T = d.T, TS = T + 1;
-  float* Ksh = smem + wave * (2 * T * HD + T * TS);
+  // small windows (T = 16): G = 64 / T heads share a wave, lane = (head group, token)
+  const int G = d.G, grp = lane64 / T, lane = lane64 - grp * T;
+  float* Ksh = smem + (wave * G + grp) * (2 * T * HD + T * TS);
   float* Vsh = Ksh + T * HD;
   float* Ssh = Vsh + T * HD;
   int bid = blockIdx.x;
@@ -104,11 +106,12 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
   const int n = bid / d.nwy;
   const long long HW = (long long)d.H * d.W;
   const float* base = d.qkv + (long long)n * 3 * d.C * HW;
-  const bool active = lane < T;
-  const Tok me = token(d, wy, wx, active ? lane : 0);
+  const Tok me = token(d, wy, wx, lane);
   const int tw = 2 * d.ws - 1;
 
-  for (int head = wave; head < d.heads; head += nwaves) {
+  for (int head0 = wave * G; head0 < d.heads; head0 += nwaves * G) {
+    const int head = min(head0 + grp, d.heads - 1);
+    const bool active = grp < G && head0 + grp < d.heads;
     const float* qp = base + (long long)(head * HD) * HW;
     const float* kp = base + (long long)(d.C + head * HD) * HW;
     const float* vp = base + (long long)(2 * d.C + head * HD) * HW;
@@ -159,11 +162,12 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
 template <int HD>
 __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int T = d.T, TS = T + 1;
   const int tw = 2 * d.ws - 1, ntab = tw * tw;
-  const int per_wave = 4 * T * HD + T * TS + ((ntab + 3) & ~3);   // keep every wave's slab 16-B aligned (b128 reads)
-  float* Ksh = smem + wave * per_wave;
+  const int per_wave = 4 * T * HD + T * TS + ((ntab + 3) & ~3);   // keep every slab 16-B aligned (b128 reads)
+  const int G = d.G, grp = lane64 / T, lane = lane64 - grp * T;     // G heads per wave for small windows
+  float* Ksh = smem + (wave * G + grp) * per_wave;
   float* Vsh = Ksh + T * HD;
   float* Qsh = Vsh + T * HD;   // scaled q
   float* Gsh = Qsh + T * HD;   // dO
@@ -176,16 +180,18 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
   const long long HW = (long long)d.H * d.W;
   const float* base = d.qkv + (long long)n * 3 * d.C * HW;
   float* dbase = d.dqkv + (long long)n * 3 * d.C * HW;
-  const bool active = lane < T;
-  const Tok me = token(d, wy, wx, active ? lane : 0);
+  const Tok me = token(d, wy, wx, lane);
 
-  for (int head = wave; head < d.heads; head += nwaves) {
+  for (int head0 = wave * G; head0 < d.heads; head0 += nwaves * G) {
+    const int head = min(head0 + grp, d.heads - 1);
+    const bool active = grp < G && head0 + grp < d.heads;
     const float* qp = base + (long long)(head * HD) * HW;
     const float* kp = base + (long long)(d.C + head * HD) * HW;
     const float* vp = base + (long long)(2 * d.C + head * HD) * HW;
     const float* gp = d.dout + ((long long)n * d.C + head * HD) * HW;
     float q[HD], go[HD];
-    for (int i = lane; i < ntab; i += 64) Bsh[i] = 0.0f;
+    if (grp < G)
+      for (int i = lane; i < ntab; i += T) Bsh[i] = 0.0f;
     if (active) {
 #pragma unroll
       for (int dd = 0; dd < HD; ++dd) {
@@ -276,10 +282,11 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
 #pragma unroll
       for (int dd = 0; dd < HD; ++dd) dk[dd * HW + me.pix] = acc[dd];
     }
-    for (int i = lane; i < ntab; i += 64) {
-      const float v = Bsh[i];
-      if (v != 0.0f) atomicAdd(d.dtable + i * d.heads + head, v);
-    }
+    if (active)
+      for (int i = lane; i < ntab; i += T) {
+        const float v = Bsh[i];
+        if (v != 0.0f) atomicAdd(d.dtable + i * d.heads + head, v);
+      }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
   }
@@ -306,6 +313,7 @@ static int fill_desc(WaDesc& d, int N, int C, int H, int W, int heads, int ws, i
   if (ws * ws > 64) return ICM_ERR_UNSUPPORTED;
   d.N = N; d.C = C; d.H = H; d.W = W; d.heads = heads; d.ws = ws; d.shift = shift; d.hd = C / heads;
   d.T = ws * ws; d.nwx = W / ws; d.nwy = H / ws;
+  d.G = 64 / d.T;   // heads per wave (1 for 8x8 windows, 4 for 4x4)
   d.scale = 1.0f / sqrtf((float)d.hd);
   return ICM_OK;
 }
@@ -324,8 +332,8 @@ int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int
   d.qkv = qkv; d.table = table; d.out = out;
   WaFn f, b;
   if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
-  const int waves = std::min(4, heads);
-  const size_t lds = (size_t)waves * (2 * d.T * d.hd + d.T * (d.T + 1)) * 4;
+  const int waves = std::min(4, (heads + d.G - 1) / d.G);
+  const size_t lds = (size_t)waves * d.G * (2 * d.T * d.hd + d.T * (d.T + 1)) * 4;
   if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(f, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
@@ -342,9 +350,9 @@ int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, flo
   d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable = dtable;
   WaFn f, b;
   if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
-  const int waves = std::min(2, heads);
+  const int waves = std::min(2, (heads + d.G - 1) / d.G);
   const int tw = 2 * ws - 1;
-  const size_t lds = (size_t)waves * (4 * d.T * d.hd + d.T * (d.T + 1) + ((tw * tw + 3) & ~3)) * 4;
+  const size_t lds = (size_t)waves * d.G * (4 * d.T * d.hd + d.T * (d.T + 1) + ((tw * tw + 3) & ~3)) * 4;
   if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
