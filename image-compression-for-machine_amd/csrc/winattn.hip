@@ -165,14 +165,17 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
   const int tid = threadIdx.x, lane64 = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int T = d.T, TS = T + 1;
   const int tw = 2 * d.ws - 1, ntab = tw * tw;
-  const int per_wave = 4 * T * HD + T * TS + ((ntab + 3) & ~3);   // keep every slab 16-B aligned (b128 reads)
+  // LDS per head: K | V | dO | S.  Two regions are recycled so that two workgroups fit one CU (35 KB per head for
+  // 8x8 windows): dO is dead after dV -> it becomes the per-head table-gradient accumulator; V is dead after
+  // dP / dq -> the scaled q (kept in registers until then) is parked there for dK.
+  const int per_wave = (3 * T * HD + T * TS + 3) & ~3;   // keep every slab 16-B aligned (b128 reads)
   const int G = d.G, grp = lane64 / T, lane = lane64 - grp * T;     // G heads per wave for small windows
   float* Ksh = smem + (wave * G + grp) * per_wave;
   float* Vsh = Ksh + T * HD;
-  float* Qsh = Vsh + T * HD;   // scaled q
-  float* Gsh = Qsh + T * HD;   // dO
+  float* Gsh = Vsh + T * HD;   // dO
   float* Ssh = Gsh + T * HD;   // P then dS
-  float* Bsh = Ssh + T * TS;   // per-head table gradient
+  float* Qsh = Vsh;            // scaled q, written after the dq phase
+  float* Bsh = Gsh;            // per-head table gradient, zeroed after the dV phase
   int bid = blockIdx.x;
   const int wx = bid % d.nwx; bid /= d.nwx;
   const int wy = bid % d.nwy;
@@ -190,14 +193,11 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
     const float* vp = base + (long long)(2 * d.C + head * HD) * HW;
     const float* gp = d.dout + ((long long)n * d.C + head * HD) * HW;
     float q[HD], go[HD];
-    if (grp < G)
-      for (int i = lane; i < ntab; i += T) Bsh[i] = 0.0f;
     if (active) {
 #pragma unroll
       for (int dd = 0; dd < HD; ++dd) {
         q[dd] = qp[dd * HW + me.pix] * d.scale;
         go[dd] = gp[dd * HW + me.pix];
-        Qsh[lane * HD + dd] = q[dd];
         Gsh[lane * HD + dd] = go[dd];
         Ksh[lane * HD + dd] = kp[dd * HW + me.pix];
         Vsh[lane * HD + dd] = vp[dd * HW + me.pix];
@@ -244,6 +244,10 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
+    if (grp < G)   // dO rows are dead: the region now accumulates the table gradient
+      for (int i = lane; i < ntab; i += T) Bsh[i] = 0.0f;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
     // ---- dP, delta, dS (row per lane), dq, table gradient
     if (active) {
       float delta = 0.0f;
@@ -266,6 +270,12 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
       float* dqp = dbase + (long long)(head * HD) * HW;
 #pragma unroll
       for (int dd = 0; dd < HD; ++dd) dqp[dd * HW + me.pix] = dq[dd] * d.scale;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (active) {   // V rows are dead: park the scaled q there for the dK sweep
+#pragma unroll
+      for (int dd = 0; dd < HD; ++dd) Qsh[lane * HD + dd] = q[dd];
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -352,7 +362,8 @@ int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, flo
   if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
   const int waves = std::min(2, (heads + d.G - 1) / d.G);
   const int tw = 2 * ws - 1;
-  const size_t lds = (size_t)waves * d.G * (4 * d.T * d.hd + d.T * (d.T + 1) + ((tw * tw + 3) & ~3)) * 4;
+  if (tw * tw > d.T * d.hd) return ICM_ERR_UNSUPPORTED;   // the table gradient is accumulated in the dO region
+  const size_t lds = (size_t)waves * d.G * ((3 * d.T * d.hd + d.T * (d.T + 1) + 3) & ~3) * 4;
   if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
