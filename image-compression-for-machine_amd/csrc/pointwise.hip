@@ -288,6 +288,58 @@ __global__ void residual_scale_kernel(const float* __restrict__ shortcut, const 
     out[i] = (shortcut ? shortcut[i] : 0.0f) + s * branch[i];
   }
 }
+// ---------------------------------------------------------------- thin-channel convolutions as GEMM + (im2col | col2im)
+// The 3-channel ends of the codec (g_a.0: conv 3->192, g_s.8: convT 192->3; cnn.py:32,51) waste 90 % of a 32-row MFMA
+// tile in the implicit-GEMM kernel.  Their (channel, tap) pairs become the channel axis of a 1x1 GEMM instead:
+//   im2col:  cols[n][c*KK + t][oy][ox] = x[n][c][oy*S - pad + kh][ox*S - pad + kw]        (0 outside)
+//   col2im:  out[n][c][y][x] = bias[c] + sum_t cols[n][c*KK + t][(y + pad - kh)/S][(x + pad - kw)/S]   (adjoint map)
+// Both are one pass over the 75-channel column tensor (HBM-bound, coalesced along x).
+__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ cols, int N, int C, int H, int W, int OH,
+                              int OW, int K, int S, int pad) {
+  const int KK = K * K;
+  const long long total = (long long)N * C * KK * OH * OW;
+  GRID_STRIDE(i, total) {
+    const int ox = (int)(i % OW);
+    long long q = i / OW;
+    const int oy = (int)(q % OH); q /= OH;
+    const int ct = (int)(q % (C * KK));
+    const int n = (int)(q / (C * KK));
+    const int c = ct / KK, t = ct - c * KK, kh = t / K, kw = t - kh * K;
+    const int iy = oy * S - pad + kh, ix = ox * S - pad + kw;
+    float v = 0.0f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long long)n * C + c) * H + iy) * W + ix];
+    cols[i] = v;
+  }
+}
+__global__ void col2im_kernel(const float* __restrict__ cols, const float* __restrict__ bias, float* __restrict__ out,
+                              int N, int C, int H, int W, int OH, int OW, int K, int S, int pad, int accum) {
+  const int KK = K * K;
+  const long long total = (long long)N * C * H * W;
+  GRID_STRIDE(i, total) {
+    const int x = (int)(i % W);
+    long long q = i / W;
+    const int y = (int)(q % H); q /= H;
+    const int c = (int)(q % C);
+    const int n = (int)(q / C);
+    float v = bias ? bias[c] : 0.0f;
+    const float* cp = cols + ((long long)n * C + c) * KK * OH * OW;
+    for (int kh = 0; kh < K; ++kh) {
+      const int ty = y + pad - kh;
+      if (ty < 0 || ty % S != 0) continue;
+      const int oy = ty / S;
+      if (oy >= OH) continue;
+      for (int kw = 0; kw < K; ++kw) {
+        const int tx = x + pad - kw;
+        if (tx < 0 || tx % S != 0) continue;
+        const int ox = tx / S;
+        if (ox >= OW) continue;
+        v += cp[((long long)(kh * K + kw) * OH + oy) * OW + ox];
+      }
+    }
+    if (accum) v += out[i];
+    out[i] = v;
+  }
+}
 __global__ void fill_kernel(float* p, long long n, float v) {
   GRID_STRIDE(i, n) p[i] = v;
 }
@@ -504,6 +556,25 @@ int icm_residual_scale(const float* shortcut, const float* branch, const float* 
   if (!branch || !scale || !out || N <= 0 || per_sample <= 0) return ICM_ERR_ARG;
   hipLaunchKernelGGL(residual_scale_kernel, dim3(grid_for((long long)N * per_sample)), dim3(256), 0, ST, shortcut,
                      branch, scale, out, (long long)per_sample, (long long)N * per_sample);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_im2col(const float* x, float* cols, int N, int C, int H, int W, int K, int stride, int pad, void* stream) {
+  if (!x || !cols || N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || stride <= 0 || pad < 0) return ICM_ERR_ARG;
+  const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+  if (OH <= 0 || OW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for((long long)N * C * K * K * OH * OW)), dim3(256), 0, ST, x, cols, N, C, H,
+                     W, OH, OW, K, stride, pad);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_col2im(const float* cols, const float* bias, float* out, int N, int C, int H, int W, int K, int stride, int pad,
+               int accum, void* stream) {
+  if (!cols || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || stride <= 0 || pad < 0) return ICM_ERR_ARG;
+  const int OH = (H + 2 * pad - K) / stride + 1, OW = (W + 2 * pad - K) / stride + 1;
+  if (OH <= 0 || OW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long long)N * C * H * W, 1)), dim3(256), 0, ST, cols, bias, out, N, C,
+                     H, W, OH, OW, K, stride, pad, accum);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -68,7 +68,7 @@ SYMBOLS = [
     "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_layernorm_fwd", "icm_layernorm_bwd", "icm_space_to_depth2",
-    "icm_residual_scale", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
+    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
 ]
@@ -112,6 +112,8 @@ def lib():
         L.icm_layernorm_bwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp]
         L.icm_space_to_depth2.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.icm_residual_scale.argtypes = [vp, vp, vp, vp, i32, i64, vp]
+        L.icm_im2col.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.icm_col2im.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_copy_strided.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, vp]
         L.icm_winattn_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_winattn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

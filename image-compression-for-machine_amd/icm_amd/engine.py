@@ -283,12 +283,16 @@ def copy_into(tape, src, dst, accum=0):
 
 # ------------------------------------------------------------------------------------------------ conv family
 def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, output_padding=0, res: Optional[VT] = None,
-           out=None, pixel_shuffle=0, lrp_aux=None) -> torch.Tensor:
+           out=None, pixel_shuffle=0, lrp_aux=None, w_as: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """nn.Conv2d / nn.ConvTranspose2d / nn.Linear(on NCHW) forward with fused neighbours.  Returns the
-    pre-activation output tensor (or y_hat for the LRP epilogue)."""
+    pre-activation output tensor (or y_hat for the LRP epilogue).  w_as=(d0, d1): use the (contiguous) weight as a
+    [d0, d1, 1, 1] matrix (thin-channel layers run as 1x1 GEMMs over (channel, tap) pairs); gradients still land in
+    the weight's own buffer."""
     x, act = xv.t, xv.act
     N, Cin, H, W = x.shape
     w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+    if w_as is not None:
+        w4 = w.view(w_as[0], w_as[1], 1, 1)
     if not transposed:
         Cout, ci, KH, KW = w4.shape
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
@@ -370,6 +374,62 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
 
     tape.bw.append(bwd)
     return y
+
+
+def conv2d_thin_in(tape: Tape, x, w, b, *, stride, pad) -> torch.Tensor:
+    """Conv2d with very few input channels (g_a.0: 3 -> 192, 5x5 s2; cnn.py:32) as im2col + 1x1 GEMM over the
+    Cin*K*K (channel, tap) pairs: the implicit-GEMM kernel would pad 3 channels to an 8-channel K-chunk per tap and
+    its wgrad a 3-wide N tile to 32."""
+    N, Cin, H, W = x.shape
+    Cout, ci, K, K2 = w.shape
+    if ci != Cin or K != K2:
+        raise ValueError("conv2d_thin_in: weight / input mismatch")
+    OH, OW = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    xc = x if x.is_contiguous() else x.contiguous()
+    cols = torch.empty((N, Cin * K * K, OH, OW), dtype=torch.float32, device=x.device)
+    check(L.lib().icm_im2col(ptr(xc), ptr(cols), N, Cin, H, W, K, stride, pad, tape.st), "im2col")
+    if tape.need_grad:
+        if tape.wants(x):
+            def bwd():
+                g = tape.grad_of(cols)
+                if g is None:
+                    return
+                dx, acc = tape.grad_for_write(x)
+                assert dx.is_contiguous() and g.is_contiguous()
+                check(L.lib().icm_col2im(ptr(g), 0, ptr(dx), N, Cin, H, W, K, stride, pad, acc, tape.st), "col2im")
+            tape.bw.append(bwd)
+        else:
+            tape.stop(cols)
+    return conv2d(tape, VT(cols), w, b, w_as=(Cout, Cin * K * K))
+
+
+def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -> torch.Tensor:
+    """ConvTranspose2d with very few output channels (g_s.8: 192 -> 3, 5x5 s2; cnn.py:51) as a 1x1 GEMM producing the
+    Cout*K*K per-tap contributions of every input pixel, then one col2im pass (+ bias)."""
+    x = xv.t
+    N, Cin, H, W = x.shape
+    ci, Cout, K, K2 = w.shape
+    if ci != Cin or K != K2:
+        raise ValueError("convT2d_thin_out: weight / input mismatch")
+    OH = (H - 1) * stride - 2 * pad + K + output_padding
+    OW = (W - 1) * stride - 2 * pad + K + output_padding
+    tmp = conv2d(tape, xv, w, None, transposed=True, stride=1, pad=0, w_as=(Cin, Cout * K * K))
+    out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+    check(L.lib().icm_col2im(ptr(tmp), ptr(b), ptr(out), N, Cout, OH, OW, K, stride, pad, 0, tape.st), "col2im")
+    if tape.need_grad:
+        def bwd():
+            dy = tape.grad_of(out)
+            if dy is None:
+                return
+            dy = dy if dy.is_contiguous() else dy.contiguous()
+            if b is not None and tape.wants(b):
+                gb_, acc = tape.grad_for_write(b)
+                check(L.lib().icm_channel_sum(ptr(dy), bs(dy), N, Cout, OH * OW, ptr(gb_), acc, tape.st), "channel_sum")
+            dt, acc = tape.grad_for_write(tmp)
+            assert acc == 0
+            check(L.lib().icm_im2col(ptr(dy), ptr(dt), N, Cout, OH, OW, K, stride, pad, tape.st), "im2col")
+        tape.bw.append(bwd)
+    return out
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,

@@ -197,7 +197,7 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
                   bucket_marks: Optional[dict] = None):
     """WACNN.forward (models/cnn.py:141-189) on the HIP engine -> (x_hat, y_likelihoods, z_likelihoods)."""
     # ---- g_a (cnn.py:31-41)
-    t = E.conv2d(tape, VT(x), P["g_a.0.weight"], P["g_a.0.bias"], stride=2, pad=2)
+    t = E.conv2d_thin_in(tape, x, P["g_a.0.weight"], P["g_a.0.bias"], stride=2, pad=2)
     t = E.gdn(tape, t, P["g_a.1.beta"], P["g_a.1.gamma"], False)
     t = E.conv2d(tape, VT(t), P["g_a.2.weight"], P["g_a.2.bias"], stride=2, pad=2)
     t = E.gdn(tape, t, P["g_a.3.beta"], P["g_a.3.gamma"], False)
@@ -216,8 +216,7 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
     t = E.attention_gate(tape, t, P, "g_s.5", 8, 8, 4)
     t = E.conv2d(tape, VT(t), P["g_s.6.weight"], P["g_s.6.bias"], stride=2, pad=2, transposed=True, output_padding=1)
     t = E.gdn(tape, t, P["g_s.7.beta"], P["g_s.7.gamma"], True)
-    x_hat = E.conv2d(tape, VT(t), P["g_s.8.weight"], P["g_s.8.bias"], stride=2, pad=2, transposed=True,
-                     output_padding=1)
+    x_hat = E.convT2d_thin_out(tape, VT(t), P["g_s.8.weight"], P["g_s.8.bias"], stride=2, pad=2, output_padding=1)
     if tape.need_grad:
         _split_lik(tape, Y_lik, num_slices)
     return x_hat, Y_lik, z_lik
@@ -267,7 +266,7 @@ def stf_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise
     if x.shape[2] % 2 or x.shape[3] % 2:
         raise ValueError("stf_forward: odd image sizes need PatchEmbed padding (inputs are multiples of 64)")
     # ---- patch_embed (stf.py:331-351): conv 2x2 s2 + LayerNorm
-    t = E.conv2d(tape, VT(x), P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=2, pad=0)
+    t = E.conv2d_thin_in(tape, x, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=2, pad=0)
     t = E.layernorm(tape, t, P["patch_embed.norm.weight"], P["patch_embed.norm.bias"])
     for i in range(4):
         t = _basic_layer(tape, P, f"layers.{i}", t, STF_DEPTHS[i], STF_HEADS[i], window, "merge" if i < 3 else None,

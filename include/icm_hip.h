@@ -164,6 +164,17 @@ int icm_space_to_depth2(const float* src, float* dst, int N, int C, int H, int W
 int icm_residual_scale(const float* shortcut, const float* branch, const float* scale, float* out, int N,
                        int64_t per_sample, void* stream);
 
+/* ---- thin-channel convolutions (the 3-channel ends g_a.0 / g_s.8, cnn.py:32,51) as 1x1 GEMM + column passes ----
+ * im2col: cols[n][c*K*K + kh*K + kw][oy][ox] = x[n][c][oy*stride - pad + kh][ox*stride - pad + kw] (0 outside);
+ *   x [N,C,H,W] -> cols [N, C*K*K, OH, OW], OH = (H + 2*pad - K)/stride + 1.  Forward of a Conv2d with few input
+ *   channels (then a 1x1 GEMM over C*K*K channels), and the gradient of icm_col2im.
+ * col2im (adjoint): out[n][c][y][x] (+)= bias[c] + sum over taps with (y+pad-kh) % stride == 0 of
+ *   cols[n][c*K*K + t][(y+pad-kh)/stride][(x+pad-kw)/stride]; cols [N, C*K*K, OH, OW] -> out [N,C,H,W].  Tail of a
+ *   ConvTranspose2d with few output channels (models/utils.py:124-132), and the gradient of icm_im2col. */
+int icm_im2col(const float* x, float* cols, int N, int C, int H, int W, int K, int stride, int pad, void* stream);
+int icm_col2im(const float* cols, const float* bias, float* out, int N, int C, int H, int W, int K, int stride, int pad,
+               int accum, void* stream);
+
 /* ---- window attention core (layers/win_attention.py:84-115,153-207) --------------------------
  * qkv: [N][3*C][H][W] (output of the qkv Linear run as a 1x1 conv on NCHW; channel = which*C + head*hd + d)
  * out: [N][C][H][W] (channel = head*hd + d), input of the proj Linear.  Cyclic shift, window partition,

@@ -375,3 +375,56 @@ def test_rd_loss_and_adam():
         close(pg, p, 1e-6, what=f"adam p step {step}")
         close(mg, m, 1e-5, what="adam m")
         close(vg, v, 1e-5, what="adam v")
+
+
+# ------------------------------------------------------------------------------------------ thin-channel ends
+def _tape_run(fn, inputs, g):
+    """fn(tape, *device_tensors) -> y; backward seeded with g; returns (y, [grad of each input])"""
+    from icm_amd import engine as E
+    tape = E.Tape(need_grad=True)
+    ts = [t.to(dev()) for t in inputs]
+    y = fn(tape, *ts)
+    tape.bind_grad(y, g.to(dev()).contiguous(), True)
+    tape.backward()
+    torch.cuda.synchronize()
+    return y, [tape.grad_of(t) for t in ts]
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 20, 24, 40, 5, 2), (1, 3, 16, 16, 192, 5, 2), (2, 2, 9, 11, 33, 3, 1)])
+def test_conv_thin_in_vs_torch(shape):
+    """g_a.0-style Conv2d (few input channels) as im2col + 1x1 GEMM: forward, dgrad (col2im), wgrad, bias grad"""
+    from icm_amd import engine as E
+    N, Cin, H, Wd, Cout, k, s = shape
+    x = U("thin.x", (N, Cin, H, Wd), -1.0, 1.0)
+    w = U("thin.w", (Cout, Cin, k, k), -0.3, 0.3)
+    b = U("thin.b", (Cout,), -0.5, 0.5)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=s, padding=k // 2)
+    g = U("thin.g", yr.shape, -1.0, 1.0)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], g)
+    y, (gx, gw, gb) = _tape_run(lambda t, xx, ww, bb: E.conv2d_thin_in(t, xx, ww, bb, stride=s, pad=k // 2), [x, w, b], g)
+    close(y, yr, what="y")
+    close(gx, gxr, what="gx")
+    close(gw, gwr, what="gw", tol=1e-4)
+    close(gb, gbr, what="gb", tol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 10, 12, 3, 5, 2), (1, 192, 8, 8, 3, 5, 2), (2, 16, 7, 9, 2, 3, 1)])
+def test_convT_thin_out_vs_torch(shape):
+    """g_s.8-style ConvTranspose2d (few output channels) as 1x1 GEMM + col2im: forward, dgrad, wgrad, bias grad"""
+    from icm_amd import engine as E
+    from icm_amd.engine import VT
+    N, Cin, H, Wd, Cout, k, s = shape
+    x = U("thinT.x", (N, Cin, H, Wd), -1.0, 1.0)
+    w = U("thinT.w", (Cin, Cout, k, k), -0.3, 0.3)
+    b = U("thinT.b", (Cout,), -0.5, 0.5)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=k // 2, output_padding=s - 1)
+    g = U("thinT.g", yr.shape, -1.0, 1.0)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], g)
+    y, (gx, gw, gb) = _tape_run(lambda t, xx, ww, bb: E.convT2d_thin_out(t, VT(xx), ww, bb, stride=s, pad=k // 2,
+                                                                          output_padding=s - 1), [x, w, b], g)
+    close(y, yr, what="y")
+    close(gx, gxr, what="gx")
+    close(gw, gwr, what="gw", tol=1e-4)
+    close(gb, gbr, what="gb", tol=1e-4)
