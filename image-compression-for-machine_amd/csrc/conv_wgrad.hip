@@ -41,7 +41,10 @@ struct WgDesc {
   int pe[32];                  // patch offset of pixel 2kp (wave-uniform: scalar loads)
 };
 
-template <int TA, int TB, int NACC>
+// WS (1x1 problems): every MFMA wave holds ALL TA x TB tiles and takes every 4th pixel pair; its partial sums go to
+// its own slab (split * 4 + wave), so the existing slab reduction also sums the waves.  96 x 96 tiles fit the codec's
+// channel counts (96 / 192 / 576, 160 / 320) far better than 128 x 128 and keep the four waves balanced (9 tiles).
+template <int TA, int TB, int NACC, bool WS = false>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PatchGeom& pg = d.pg;
@@ -156,6 +159,74 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
 
   // ------------------------------------------------------------------ MFMA waves
   const int h = lane >> 5, l31 = lane & 31;
+  if constexpr (WS) {
+    static_assert(NACC == TA * TB, "wave-split mode: one accumulator per tile");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int boffs[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) boffs[tb] = (tb * 32 + l31) * pg.CS + d.tapoff[t0] + h * d.po_h;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int pe_lane = d.pe[lane & 31];
+    __syncthreads();  // tile 0 staged
+    const int nkp = npx >> 1;   // 32 for the 64-pixel tiles this mode is planned with: 8 pairs per wave
+    for (int it = 0; it < niter; ++it) {
+      const float* gsT = smem + (it & 1) * bufsz;
+      const float* gbP = gsT + gs_sz;
+      const float* arow = gsT + l31 * grow + h;
+      float avA[TA], bvA[TB], avB[TA], bvB[TB];
+      auto fetch = [&](float (&av)[TA], float (&bv)[TB], int kn) {
+        const int po = __builtin_amdgcn_readlane(pe_lane, kn);
+#pragma unroll
+        for (int u = 0; u < TA; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
+#pragma unroll
+        for (int u = 0; u < TB; ++u) bv[u] = gbP[boffs[u] + po];
+      };
+      auto mma = [&](const float (&av)[TA], const float (&bv)[TB]) {
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb)
+            acc[ta * TB + tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta * TB + tb], 0, 0, 0);
+      };
+      fetch(avA, bvA, wave_u);
+      for (int kp = wave_u; kp < nkp; kp += 8) {
+        fetch(avB, bvB, min(kp + 4, nkp - 1));
+        mma(avA, bvA);
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        fetch(avA, bvA, min(kp + 8, nkp - 1));
+        if (kp + 4 < nkp) mma(avB, bvB);
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const int ta = i / TB, tb = i % TB;
+      const int b = b0 + tb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (a < d.Ca && b < pg.C)
+          G.ws[(((long long)(split * 4 + wave_u) * d.ntaps + t0) * d.Ca + a) * pg.C + b] = acc[i][r];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   // accumulator i of this wave: tile q = wave + 4*i -> (tap, ta, tb); all wave-uniform
   const int ntile = nt * TA * TB;
   int boffs[NACC];
@@ -179,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   // A tile of accumulator i: tile q = wave + 4*i has ta = (q % (TA*TB)) / TB, which is `i` for the 4x4 (1x1-conv)
   // configuration and wave-uniform otherwise (TA*TB divides 4) -> no per-MFMA operand select, one A read per pair
   constexpr bool kPerAcc = (TA * TB == 16);
-  static_assert(kPerAcc ? (NACC == 4 && TA == 4) : (4 % (TA * TB) == 0), "tile -> A-row mapping");
+  static_assert(WS || (kPerAcc ? (NACC == 4 && TA == 4) : (4 % (TA * TB) == 0)), "tile -> A-row mapping");
   constexpr int NA = kPerAcc ? TA : 1;
   const int ta_w = kPerAcc ? 0 : (wave % (TA * TB)) / TB;
   __syncthreads();  // tile 0 staged
@@ -256,7 +327,7 @@ struct RedPtrs {
 };
 struct RedDesc {
   RedPtrs g[WG_MAXG];
-  int Ca, Cb, ntaps, nsplit, nwblocks;
+  int Ca, Cb, ntaps, nsplit, nsplit_bias, nwblocks, rows;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   __shared__ float tile[WG_MAX_TAPS][33];
@@ -267,20 +338,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
     const int a = ((int)blockIdx.x - d.nwblocks) * 256 + threadIdx.x;
     if (a >= Ca) return;
     float s = 0.0f;
-    for (int k = 0; k < nsplit; ++k) s += G.dbias_ws[(long long)k * Ca + a];
+    for (int k = 0; k < d.nsplit_bias; ++k) s += G.dbias_ws[(long long)k * Ca + a];
     if (G.accum_bias) s += G.dbias[a];
     G.dbias[a] = s;
     return;
   }
+  // workgroup = R consecutive a-rows x 32 b's x all taps, R = rows that fill the 256 threads (8 for 1x1, 1 for >= 8 taps)
   const int nbt = (Cb + 31) / 32;
-  const int a = blockIdx.x / nbt, b0 = (blockIdx.x % nbt) * 32;
+  const int R = d.rows;
+  const int a0 = (blockIdx.x / nbt) * R, b0 = (blockIdx.x % nbt) * 32;
   const long long slab = (long long)Ca * Cb * ntaps;
-  for (int e = threadIdx.x; e < ntaps * 32; e += 256) {
-    const int t = e >> 5, bl = e & 31;
+  for (int e = threadIdx.x; e < R * ntaps * 32; e += 256) {
+    const int rt = e >> 5, bl = e & 31;
+    const int row = rt / ntaps, t = rt - row * ntaps;
+    const int a = a0 + row;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (b0 + bl < Cb) {
+    if (a < Ca && b0 + bl < Cb) {
       const float* p = G.ws + ((long long)t * Ca + a) * Cb + b0 + bl;
       int k = 0;
+      // the splits are independent HBM / L2 rows: keep 16 loads in flight (the kernel is latency-bound: a
+      // workgroup reads nsplit x ntaps short rows)
+      for (; k + 16 <= nsplit; k += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(k + u) * slab];
+        s0 += (v[0] + v[4]) + (v[8] + v[12]);
+        s1 += (v[1] + v[5]) + (v[9] + v[13]);
+        s2 += (v[2] + v[6]) + (v[10] + v[14]);
+        s3 += (v[3] + v[7]) + (v[11] + v[15]);
+      }
       for (; k + 4 <= nsplit; k += 4) {
         s0 += p[(k + 0) * slab];
         s1 += p[(k + 1) * slab];
@@ -289,21 +375,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
       }
       for (; k < nsplit; ++k) s0 += p[k * slab];
     }
-    tile[t][bl] = (s0 + s1) + (s2 + s3);
+    tile[rt][bl] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   const int nb = min(32, Cb - b0);
-  float* o = G.dw + ((long long)a * Cb + b0) * ntaps;
-  for (int e = threadIdx.x; e < nb * ntaps; e += 256) {
-    const int bl = e / ntaps, t = e - bl * ntaps;
-    float v = tile[t][bl];
-    if (G.accum) v += o[e];
-    o[e] = v;
+  for (int e = threadIdx.x; e < R * nb * ntaps; e += 256) {
+    const int row = e / (nb * ntaps), r2 = e - row * (nb * ntaps);
+    const int a = a0 + row;
+    if (a >= Ca) continue;
+    const int bl = r2 / ntaps, t = r2 - bl * ntaps;
+    float* o = G.dw + ((long long)a * Cb + b0) * ntaps;
+    float v = tile[row * ntaps + t][bl];
+    if (G.accum) v += o[r2];
+    o[r2] = v;
   }
 }
 
 struct WgPlan {
-  int ta, tb, nacc, tpg;
+  int ta, tb, nacc, tpg, ws;
   int lgTW, lgTH, lgTI, lgNPX, PH, PW, PP, CS;
   int tiles_x, tiles_y, tiles_n, ntiles, nsplit, natile, nbtile, ngroups;
   size_t lds;
@@ -330,7 +419,14 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
     auto lds_of = [&](int ta, int tb) {
       return (size_t)2 * (ta * 32 * ((1 << lg) + 1) + tb * 32 * p.CS) * 4;
     };
-    if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) { p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; ok = true; }
+    p.ws = 0;
+    if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) {
+      p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; ok = true;
+      // 96 x 96 wave-split tiles when they waste less of the padded (a, b) rectangle than 128 x 128
+      const double pad128 = (double)cdiv(a.Ca, 128) * 128 * cdiv(a.Cb, 128) * 128;
+      const double pad96 = (double)cdiv(a.Ca, 96) * 96 * cdiv(a.Cb, 96) * 96;
+      if (lg == 6 && pad96 * 1.05 <= pad128) { p.ta = 3; p.tb = 3; p.nacc = 9; p.ws = 1; }
+    }
     else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) { p.ta = 2; p.tb = 2; p.nacc = 9; p.tpg = ntaps; ok = true; }
     else if (lds_of(2, 1) <= 150 * 1024) {   // <=14 taps per group x 2 a-tiles = 28 tiles = 7 per MFMA wave
       p.ta = 2; p.tb = 1; p.nacc = 7; p.tpg = ntaps <= 14 ? ntaps : (ntaps + 1) / 2; ok = true;
@@ -367,7 +463,7 @@ extern "C" {
 int64_t icm_wgrad_workspace_floats_grouped(const icm_wgrad_args* a, int n) {
   icm::WgPlan p;
   if (!a || n < 1 || icm::plan_wgrad(*a, p, n)) return -1;
-  return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
+  return (int64_t)p.nsplit * (p.ws ? 4 : 1) * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
 }
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a) { return icm_wgrad_workspace_floats_grouped(a, 1); }
 
@@ -388,7 +484,8 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   if (((long long)a->N * a->gb_bs + 8LL * a->H * a->W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   const int ntaps = a->KH * a->KW;
-  const long long slab_all = (long long)p.nsplit * ntaps * a->Ca * a->Cb;
+  const int nslab = p.nsplit * (p.ws ? 4 : 1);   // wave-split mode: one slab per (pixel split, MFMA wave)
+  const long long slab_all = (long long)nslab * ntaps * a->Ca * a->Cb;
   for (int i = 0; i < n; ++i)   // the slabs (+ bias partials) of this launch's split count must fit the caller's workspace
     if (arr[i].ws_floats > 0 && arr[i].ws_floats < slab_all + (long long)p.nsplit * a->Ca) return ICM_ERR_ARG;
   WgDesc d;
@@ -441,15 +538,17 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ta == 4) fn = wgrad_kernel<4, 4, 4>;
+  if (p.ws) fn = wgrad_kernel<3, 3, 9, true>;
+  else if (p.ta == 4) fn = wgrad_kernel<4, 4, 4>;
   else if (p.tb == 2) fn = wgrad_kernel<2, 2, 9>;
   else fn = wgrad_kernel<2, 1, 7>;
   if (p.lds > 64 * 1024)
     hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, n), dim3(512), p.lds, stream, d);
   ICM_CHECK_LAUNCH();
-  r.Ca = a->Ca; r.Cb = a->Cb; r.ntaps = ntaps; r.nsplit = p.nsplit;
-  r.nwblocks = a->Ca * cdiv(a->Cb, 32);
+  r.Ca = a->Ca; r.Cb = a->Cb; r.ntaps = ntaps; r.nsplit = nslab; r.nsplit_bias = p.nsplit;
+  r.rows = ntaps <= 8 ? 8 / ntaps : 1;   // a-rows per reduce workgroup (rows x taps x 32 b's fill 256 threads)
+  r.nwblocks = cdiv(a->Ca, r.rows) * cdiv(a->Cb, 32);
   bool any_bias = false;
   for (int i = 0; i < n; ++i) any_bias |= arr[i].dbias != nullptr;
   const int rblocks = r.nwblocks + (any_bias ? cdiv(a->Ca, 256) : 0);

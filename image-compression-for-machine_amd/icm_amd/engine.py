@@ -23,6 +23,8 @@ from ._lib import (ACT_GELU, ACT_NONE, ACT_SQUARE, EPI_AXPY2, EPI_GDN, EPI_IGDN,
                    EPI_RES, EPI_RES_GELU, bs, check, ptr)
 
 PEDESTAL = 2.0 ** -36
+import os as _os
+_SKIP_WGRAD = _os.environ.get("ICM_DEBUG_SKIP_WGRAD", "0") == "1"
 
 
 def new(shape_or_like, device=None):
@@ -218,6 +220,9 @@ def flush_wgrads(tape):
     stream (after an event on the main stream): nothing on the main stream consumes them before the optimiser,
     so they fill the CUs the latency-bound dgrad chain leaves idle."""
     if not tape.wjobs:
+        return
+    if _SKIP_WGRAD:   # measurement only (ICM_DEBUG_SKIP_WGRAD=1): time the main stream without weight gradients
+        tape.wjobs = []
         return
     groups: Dict[tuple, list] = {}
     for job in tape.wjobs:
