@@ -69,6 +69,8 @@ class Tape:
         self._flushed: list = []  # keeps side-stream operands alive until the streams are joined
         self.progress_every = 0
         self.min_jobs = 8
+        self.hold_wgrads = False  # True: queue weight gradients without periodic flushes (the slice-chain section
+        #                           batches its 150 small problems by geometry at the section end)
         self.st = L.stream()
 
     # ---- gradient bookkeeping
@@ -105,7 +107,8 @@ class Tape:
         for f in reversed(self.bw):
             f()
             n += 1
-            if self.progress_every > 0 and n % self.progress_every == 0 and len(self.wjobs) >= self.min_jobs:
+            if (self.progress_every > 0 and n % self.progress_every == 0 and len(self.wjobs) >= self.min_jobs
+                    and not self.hold_wgrads):
                 flush_wgrads(self)
         self.bw = []
         flush_wgrads(self)

@@ -154,6 +154,7 @@ class Trainer:
         if self.wg_every < 0:
             self.side = None
         self._eb = None
+        self.hold_chain_wgrads = _os.environ.get("ICM_HOLD_CHAIN_WGRADS", "0") == "1"
         self._pack_seq = None     # weight-packing miss sequence of the first step (windowed batch packing afterwards)
         self.pack_window = int(_os.environ.get("ICM_PACK_WINDOW", "24"))
         self.is_stf = isinstance(model, SymmetricalTransFormer)
@@ -209,8 +210,21 @@ class Trainer:
         tape.bind_grad(y_lik, dly, True)
         tape.bind_grad(z_lik, dlz, True)
         # ---- backward with bucketed all-reduce overlapped (markers fire as the tape unwinds)
+        # bucket markers fire as the tape unwinds: flush the queued weight gradients, all-reduce the finished bucket.
+        # ICM_HOLD_CHAIN_WGRADS=1 queues the 150 small slice-chain weight gradients between marker 0 (synthesis done)
+        # and marker 1 (slice loop done) and issues them in ~15 launches of up to 32 same-geometry problems instead of
+        # ~120 launches of 1-4: measured 0.7 % SLOWER on MI355X (same-box A/B, 258.9 vs 260.7 img/s) -- the early,
+        # small launches fill CUs next to the latency-bound dgrad chain -- so the default keeps the periodic flush.
+        def mark(b):
+            if b == 1:
+                tape.hold_wgrads = False
+            E.flush_wgrads(tape)
+            tape.join_side()
+            self.reducer.launch(b)
+            if b == 0 and self.hold_chain_wgrads:
+                tape.hold_wgrads = True
         for name, idx in sorted(marks.items(), key=lambda kv: -kv[1]):
-            tape.bw.insert(idx, (lambda b=name: (E.flush_wgrads(tape), tape.join_side(), self.reducer.launch(b))))
+            tape.bw.insert(idx, (lambda b=name: mark(b)))
         tape.backward()
         self._side_ws = tape._side_ws
         if tape.pack_log is not None and self._pack_seq is None:
