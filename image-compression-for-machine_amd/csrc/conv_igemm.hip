@@ -24,7 +24,7 @@
 namespace icm {
 
 #define ICM_MAX_TAPS 32
-#define ICM_MAX_GROUPS 3
+#define ICM_MAX_GROUPS 12   /* problems of identical geometry per launch (blockIdx.y): the independent slice chains */
 
 struct ConvPtrs {
   const float* x;

@@ -441,7 +441,7 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,
-                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, accum=0):
+                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, accum=0):
     n = len(xs)
     arr = (L.ConvArgs * n)()
     for i, a in enumerate(arr):
@@ -454,16 +454,27 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
         a.transposed, a.pro_act, a.epi = int(transposed), pro_act, epi
         aux = auxs[i] if auxs is not None else None
         a.aux, a.aux_bs = ptr(aux), bs(aux)
+        y2 = y2s[i] if y2s is not None else None
+        a.y2, a.y2_bs = ptr(y2), bs(y2)
         a.accum = accum
-        if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)):
+        if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)
+                  or bs(y2) != bs(y2s[0] if y2s else None)):
             raise ValueError("grouped conv: members must share strides")
     check(L.lib().icm_conv_run_grouped(arr, n, tape.st), "conv_run_grouped")
 
 
-def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1):
-    """The same stride-1 convolution shape applied to several independent (input, weight) pairs in ONE launch
-    (cc_mean_transforms[i] || cc_scale_transforms[i], cnn.py:164-168).  Returns the list of pre-activation outputs."""
+MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_igemm.hip
+
+
+def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None):
+    """The same stride-1 convolution shape applied to several independent (input, weight) pairs in ONE launch:
+    cc_mean_transforms[i] || cc_scale_transforms[i] (cnn.py:164-168), and -- because the support of slice i is
+    y_hat_slices[:max_support] (cnn.py:161), i.e. the FIRST five slices -- all chains of the slices >= max_support at
+    once.  Members may share an input tensor (their input gradients are then summed).  outs / lrp_auxs: write into
+    the given tensors with the LRP tail (cnn.py:175-178) fused.  Returns the list of outputs."""
     n = len(xvs)
+    if n > MAX_GROUP:
+        raise ValueError("conv2d_group: too many members")
     x0, act = xvs[0].t, xvs[0].act
     N, Cin, H, W = x0.shape
     Cout, ci, KH, KW = ws[0].shape
@@ -472,9 +483,12 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1):
         raise ValueError("conv2d_group: channel mismatch")
     OH, OW = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
     wps = [tape.pack(w, Cout, Cin, KH, KW, 1, 0, 1, pad) for w in ws]
-    ys = [new((N, Cout, OH, OW), x0.device) for _ in range(n)]
+    ys = list(outs) if outs is not None else [new((N, Cout, OH, OW), x0.device) for _ in range(n)]
+    lrp = lrp_auxs is not None
+    y2s = [new((N, Cout, OH, OW), x0.device) for _ in range(n)] if lrp else None
     conv_launch_grouped(tape, [v.t for v in xvs], wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
-                        transposed=0, OH=OH, OW=OW, pro_act=act)
+                        transposed=0, OH=OH, OW=OW, pro_act=act, epi=EPI_LRP if lrp else EPI_NONE,
+                        auxs=list(lrp_auxs) if lrp else None, y2s=y2s)
     if not tape.need_grad:
         return ys
 
@@ -482,20 +496,43 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1):
         dys = [tape.grad_of(y) for y in ys]
         if any(d is None for d in dys):
             raise RuntimeError("conv2d_group: every member needs a gradient")
-        gxs, accs = [], []
+        if lrp:
+            pre = []
+            for dy, aux, y2 in zip(dys, lrp_auxs, y2s):
+                accumulate(tape, aux, dy)
+                dpre = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x0.device)
+                check(L.lib().icm_lrp_bwd(ptr(dy), bs(dy), ptr(y2), bs(y2), ptr(dpre), bs(dpre), N, Cout, OH * OW, tape.st),
+                      "lrp_bwd")
+                pre.append(dpre)
+            dys = pre
         for v, w, b, dy in zip(xvs, ws, bs_, dys):
             gw, acc = tape.grad_for_write(w)
             gb_, accb = tape.grad_for_write(b)
             wgrad_defer(tape, dy, v.t, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=1, pad=pad, act_b=act, accum=acc,
                         dbias=gb_, accum_bias=accb)
-            gx, ax = tape.grad_for_write(v.t)
-            gxs.append(gx)
-            accs.append(ax)
-        assert len(set(accs)) == 1
+        # input gradients: one grouped dgrad.  Members that share an input tensor (the fixed support of the late
+        # slices) write private buffers which are then summed into the shared gradient; distinct inputs are
+        # written (or accumulated) in place.
+        keys = [_key(v.t) for v in xvs]
+        shared = len(set(keys)) < n
+        if not shared:
+            gxs, accs = [], []
+            for v in xvs:
+                gx, ax = tape.grad_for_write(v.t)
+                gxs.append(gx)
+                accs.append(ax)
+            assert len(set(accs)) == 1
+            acc0 = accs[0]
+        else:
+            gxs = [torch.empty((N, Cin, H, W), dtype=torch.float32, device=x0.device) for _ in range(n)]
+            acc0 = 0
         wpb = [tape.pack(w, Cin, Cout, KH, KW, 0, 1, 1, pad) for w in ws]
         conv_launch_grouped(tape, dys, wpb, None, gxs, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=1, pad=pad,
                             transposed=1, OH=H, OW=W, epi=EPI_MUL_DGELU if act == ACT_GELU else EPI_NONE,
-                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, accum=accs[0])
+                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, accum=acc0)
+        if shared:
+            for v, g in zip(xvs, gxs):
+                accumulate(tape, v.t, g)
 
     tape.bw.append(bwd)
     return ys

@@ -100,7 +100,8 @@ def _copy_op(tape, src, dst):
 
 
 def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, num_slices: int,
-                 max_support: int, keep: Optional[dict] = None, bucket_marks: Optional[dict] = None):
+                 max_support: int, keep: Optional[dict] = None, bucket_marks: Optional[dict] = None,
+                 batch_tail: bool = True):
     """Hyperprior + channel-conditional slice loop shared by the cnn and stf models
     (cnn.py:144-183 == stf.py:596-637) -> (y_hat, y_likelihoods, z_likelihoods).  torch.cat / chunk become
     channel-slice views of persistent support buffers."""
@@ -149,8 +150,12 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
     mus, scs = [], []
     if bucket_marks is not None:
         bucket_marks[1] = len(tape.bw)   # => slice-chain gradients complete
-    # ---- channel-conditional slice loop (cnn.py:161-180)
-    for i in range(num_slices):
+    # ---- channel-conditional slice loop (cnn.py:161-180).  The support of slice i is y_hat_slices[:max_support]
+    # (cnn.py:161): slices 0..max_support-1 form a serial chain, but every slice >= max_support sees the SAME fixed
+    # support (latent + the first max_support slices) and is independent of its neighbours -> their chains run as
+    # grouped launches (2 * n_tail mean/scale chains, then n_tail lrp chains).
+    n_serial = min(num_slices, max_support) if batch_tail else num_slices
+    for i in range(n_serial):
         k = min(i, max_support)
         ch = slice(i * sc_, (i + 1) * sc_)
         ms, ss = MS[:, :M + sc_ * k], SS[:, :M + sc_ * k]
@@ -172,6 +177,47 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
         if keep is not None:
             mus.append(mu)
             scs.append(sc)
+    tail = list(range(n_serial, num_slices))
+    for t0 in range(0, len(tail), E.MAX_GROUP // 2):
+        idx = tail[t0:t0 + E.MAX_GROUP // 2]
+        nt = len(idx)
+        k = max_support
+        ms, ss = MS[:, :M + sc_ * k], SS[:, :M + sc_ * k]
+        # mean / scale chains of all tail slices: one grouped launch per layer
+        names = [f"cc_mean_transforms.{i}" for i in idx] + [f"cc_scale_transforms.{i}" for i in idx]
+        xvs = [VT(ms)] * nt + [VT(ss)] * nt
+        for li in (0, 2, 4, 6, 8):
+            ts = E.conv2d_group(tape, xvs, [P[f"{p}.{li}.weight"] for p in names], [P[f"{p}.{li}.bias"] for p in names],
+                                pad=1)
+            xvs = [VT(t, ACT_GELU) for t in ts]
+        mu_t, sc_t = ts[:nt], ts[nt:]
+        LSs, pres = [], []
+        for j, i in enumerate(idx):
+            ch = slice(i * sc_, (i + 1) * sc_)
+            LS = E.new((N, M + sc_ * (k + 1), h, w), dev)
+            yh_pre = LS[:, M + sc_ * k:]
+            if need:
+                dLS = E.zeros(LS.shape, dev)
+                tape.bind_grad(LS, dLS, True)
+                tape.bind_grad(LS[:, :M + sc_ * k], dLS[:, :M + sc_ * k], True)
+                tape.bind_grad(yh_pre, dLS[:, M + sc_ * k:], True)
+            _copy_op(tape, ms, LS[:, :M + sc_ * k])
+            E.gc_likelihood_ste(tape, y[:, ch], mu_t[j], sc_t[j], None if noise_y is None else noise_y[:, ch],
+                                Y_lik[:, ch], yh_pre)
+            LSs.append(LS)
+            pres.append(yh_pre)
+        # lrp chains of all tail slices, LRP tail fused into the last grouped launch
+        lnames = [f"lrp_transforms.{i}" for i in idx]
+        xvs = [VT(LS) for LS in LSs]
+        for li in (0, 2, 4, 6):
+            ts = E.conv2d_group(tape, xvs, [P[f"{p}.{li}.weight"] for p in lnames],
+                                [P[f"{p}.{li}.bias"] for p in lnames], pad=1)
+            xvs = [VT(t, ACT_GELU) for t in ts]
+        E.conv2d_group(tape, xvs, [P[f"{p}.8.weight"] for p in lnames], [P[f"{p}.8.bias"] for p in lnames], pad=1,
+                       outs=[Y_hat[:, i * sc_:(i + 1) * sc_] for i in idx], lrp_auxs=pres)
+        if keep is not None:
+            mus.extend(mu_t)
+            scs.extend(sc_t)
     if bucket_marks is not None:
         bucket_marks[0] = len(tape.bw)   # => synthesis-transform gradients complete
     if keep is not None:
