@@ -48,10 +48,11 @@ def dominant_kernel_roofline(dev, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flop = 2.0 * BATCH_PER_GPU * 192 * 192 * 25 * 64 * 64
     # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    # runs, FETCH_SIZE doubled per the gfx950 correction): tools/pmc_dominant.sh -> profiles/r01_pmc_dominant.json.
+    # runs, FETCH_SIZE doubled per the gfx950 correction): tools/pmc_dominant.sh + tools/pmc_dominant_summary.py ->
+    # profiles/r01_v9_pmc_dominant.json.
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r01_v9_pmc_dominant.json")) as fh:
             traffic = json.load(fh)["hbm_bytes_per_launch"]
     except Exception:
         pass

@@ -601,10 +601,10 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     }
   }
   if (best < 0) return ICM_ERR_UNSUPPORTED;
-  // halo convolutions with many pixels: within 15 % of the cheapest estimate, take the single-pass-over-activations
+  // halo convolutions with many pixels: within 20 % of the cheapest estimate, take the single-pass-over-activations
   // tiling (every extra co-block re-stages the whole halo patch from L2 / HBM: 1.85x FETCH_SIZE measured on g_a.2
   // for 3 % of MFMA time)
-  if (best1 >= 0 && best1_cost <= 1.15 * best_cost) {
+  if (best1 >= 0 && best1_cost <= 1.2 * best_cost) {
     best = best1;
     bg = bg1;
   }
