@@ -41,8 +41,8 @@ struct WgDesc {
   int pe[32];                  // patch offset of pixel 2kp (wave-uniform: scalar loads)
 };
 
-// WS (1x1 problems): every MFMA wave holds ALL TA x TB tiles and takes every 4th pixel pair; its partial sums go to
-// its own slab (split * 4 + wave), so the existing slab reduction also sums the waves.  96 x 96 tiles fit the codec's
+// WS (1x1 problems): every MFMA wave holds ALL TA x TB tiles and takes every 4th pixel pair; the four partial sums
+// are folded through LDS at the end.  96 x 96 tiles fit the codec's
 // channel counts (96 / 192 / 576, 160 / 320) far better than 128 x 128 and keep the four waves balanced (9 tiles).
 template <int TA, int TB, int NACC, bool WS = false>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
@@ -213,6 +213,33 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
       }
       __syncthreads();
     }
+    // the four waves hold partial sums of the same 9 tiles: fold them through LDS (free after the last tile barrier;
+    // the loaders have left, ended waves do not take part in s_barrier) so that the workgroup writes ONE slab --
+    // 4x less slab traffic and a 4x shorter reduction.  Two rounds (the staging buffers hold two accumulator sets).
+    float* red = smem;
+    constexpr int SET = NACC * 16 * 64;   // floats of one wave's accumulators
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int src0 = round == 0 ? 1 : 3;          // round 0: waves 1, 2 -> wave 0 ; round 1: wave 3 -> wave 0
+      const int nsrc = round == 0 ? 2 : 1;
+      if (wave_u >= src0 && wave_u < src0 + nsrc) {
+        float* dst = red + (wave_u - src0) * SET;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64 + lane] = acc[i][r];
+      }
+      __syncthreads();
+      if (wave_u == 0) {
+        for (int k = 0; k < nsrc; ++k)
+#pragma unroll
+          for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += red[k * SET + (i * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (wave_u != 0) return;
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       const int ta = i / TB, tb = i % TB;
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
       for (int r = 0; r < 16; ++r) {
         const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (a < d.Ca && b < pg.C)
-          G.ws[(((long long)(split * 4 + wave_u) * d.ntaps + t0) * d.Ca + a) * pg.C + b] = acc[i][r];
+          G.ws[(((long long)split * d.ntaps + t0) * d.Ca + a) * pg.C + b] = acc[i][r];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -315,8 +342,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
 }
 
 // dw[(a*Cb + b)*ntaps + t] (+)= sum_s ws[((s*ntaps + t)*Ca + a)*Cb + b]      (+ db[a] (+)= sum_s dbias_ws[s][a])
-// workgroup = one a, 32 consecutive b: reads 128-B rows per tap (4 splits in flight), transposes through LDS,
-// writes ntaps*32 contiguous floats of the canonical layout.  blockIdx.y = problem of the group; the last
+// A slab is [tap][a][b] with (a, b) contiguous, so a workgroup takes a CONTIGUOUS run of 256 (a, b) positions (1024
+// with 16-byte loads for 1x1 problems): every load instruction of a wave reads one 256-B / 1-KB segment per
+// (split, tap) -- the earlier (a-row x 32 b) tiling read 128-B pieces scattered over 64 split slabs and ran at
+// 0.2 TB/s.  Splits are independent rows: 8 loads in flight per thread.  Taps are transposed through LDS so that the
+// canonical [a][b][kh][kw] layout is written in contiguous runs.  blockIdx.y = problem of the group; the last
 // blockIdx.x rows of the grid reduce the fused bias gradients.
 struct RedPtrs {
   const float* ws;
@@ -327,12 +357,12 @@ struct RedPtrs {
 };
 struct RedDesc {
   RedPtrs g[WG_MAXG];
-  int Ca, Cb, ntaps, nsplit, nsplit_bias, nwblocks, rows;
+  int Ca, Cb, ntaps, nsplit, nsplit_bias, nwblocks, vec4;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
-  __shared__ float tile[WG_MAX_TAPS][33];
+  __shared__ float tile[WG_MAX_TAPS][257];
   const RedPtrs G = d.g[blockIdx.y];
-  const int Ca = d.Ca, Cb = d.Cb, ntaps = d.ntaps, nsplit = d.nsplit;
+  const int Ca = d.Ca, ntaps = d.ntaps, nsplit = d.nsplit;
   if ((int)blockIdx.x >= d.nwblocks) {   // bias part
     if (!G.dbias) return;
     const int a = ((int)blockIdx.x - d.nwblocks) * 256 + threadIdx.x;
@@ -343,51 +373,54 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
     G.dbias[a] = s;
     return;
   }
-  // workgroup = R consecutive a-rows x 32 b's x all taps, R = rows that fill the 256 threads (8 for 1x1, 1 for >= 8 taps)
-  const int nbt = (Cb + 31) / 32;
-  const int R = d.rows;
-  const int a0 = (blockIdx.x / nbt) * R, b0 = (blockIdx.x % nbt) * 32;
-  const long long slab = (long long)Ca * Cb * ntaps;
-  for (int e = threadIdx.x; e < R * ntaps * 32; e += 256) {
-    const int rt = e >> 5, bl = e & 31;
-    const int row = rt / ntaps, t = rt - row * ntaps;
-    const int a = a0 + row;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (a < Ca && b0 + bl < Cb) {
-      const float* p = G.ws + ((long long)t * Ca + a) * Cb + b0 + bl;
-      int k = 0;
-      // the splits are independent HBM / L2 rows: keep 16 loads in flight (the kernel is latency-bound: a
-      // workgroup reads nsplit x ntaps short rows)
-      for (; k + 16 <= nsplit; k += 16) {
-        float v[16];
+  const long long CaCb = (long long)Ca * d.Cb;
+  const long long slab = CaCb * ntaps;
+  if (d.vec4) {   // 1x1 problems, 16-byte aligned: thread = 4 consecutive (a, b) positions
+    const long long ab = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (ab >= CaCb) return;
+    const float* p = G.ws + ab;
+    f32x4 s = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+      f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(k + u) * slab];
-        s0 += (v[0] + v[4]) + (v[8] + v[12]);
-        s1 += (v[1] + v[5]) + (v[9] + v[13]);
-        s2 += (v[2] + v[6]) + (v[10] + v[14]);
-        s3 += (v[3] + v[7]) + (v[11] + v[15]);
-      }
-      for (; k + 4 <= nsplit; k += 4) {
-        s0 += p[(k + 0) * slab];
-        s1 += p[(k + 1) * slab];
-        s2 += p[(k + 2) * slab];
-        s3 += p[(k + 3) * slab];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (k + u) * slab);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(p + k * slab);
+    f32x4* o = reinterpret_cast<f32x4*>(G.dw + ab);
+    if (G.accum) s += *o;
+    *o = s;
+    return;
+  }
+  const long long ab0 = (long long)blockIdx.x * 256;
+  const long long ab = ab0 + threadIdx.x;
+  const bool valid = ab < CaCb;
+  for (int t = 0; t < ntaps; ++t) {
+    float s0 = 0.0f, s1 = 0.0f;
+    if (valid) {
+      const float* p = G.ws + (long long)t * CaCb + ab;
+      int k = 0;
+      for (; k + 8 <= nsplit; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * slab];
+        s0 += (v[0] + v[2]) + (v[4] + v[6]);
+        s1 += (v[1] + v[3]) + (v[5] + v[7]);
       }
       for (; k < nsplit; ++k) s0 += p[k * slab];
     }
-    tile[rt][bl] = (s0 + s1) + (s2 + s3);
+    tile[t][threadIdx.x] = s0 + s1;
   }
   __syncthreads();
-  const int nb = min(32, Cb - b0);
-  for (int e = threadIdx.x; e < R * nb * ntaps; e += 256) {
-    const int row = e / (nb * ntaps), r2 = e - row * (nb * ntaps);
-    const int a = a0 + row;
-    if (a >= Ca) continue;
-    const int bl = r2 / ntaps, t = r2 - bl * ntaps;
-    float* o = G.dw + ((long long)a * Cb + b0) * ntaps;
-    float v = tile[row * ntaps + t][bl];
-    if (G.accum) v += o[r2];
-    o[r2] = v;
+  const int nv = (int)min((long long)256, CaCb - ab0);
+  float* o = G.dw + ab0 * ntaps;
+  for (int e = threadIdx.x; e < nv * ntaps; e += 256) {
+    const int abl = e / ntaps, t = e - abl * ntaps;
+    float v = tile[t][abl];
+    if (G.accum) v += o[e];
+    o[e] = v;
   }
 }
 
@@ -463,7 +496,7 @@ extern "C" {
 int64_t icm_wgrad_workspace_floats_grouped(const icm_wgrad_args* a, int n) {
   icm::WgPlan p;
   if (!a || n < 1 || icm::plan_wgrad(*a, p, n)) return -1;
-  return (int64_t)p.nsplit * (p.ws ? 4 : 1) * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
+  return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
 }
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a) { return icm_wgrad_workspace_floats_grouped(a, 1); }
 
@@ -484,7 +517,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   if (((long long)a->N * a->gb_bs + 8LL * a->H * a->W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   const int ntaps = a->KH * a->KW;
-  const int nslab = p.nsplit * (p.ws ? 4 : 1);   // wave-split mode: one slab per (pixel split, MFMA wave)
+  const int nslab = p.nsplit;   // (wave-split mode folds its four waves through LDS: still one slab per pixel split)
   const long long slab_all = (long long)nslab * ntaps * a->Ca * a->Cb;
   for (int i = 0; i < n; ++i)   // the slabs (+ bias partials) of this launch's split count must fit the caller's workspace
     if (arr[i].ws_floats > 0 && arr[i].ws_floats < slab_all + (long long)p.nsplit * a->Ca) return ICM_ERR_ARG;
@@ -547,8 +580,14 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, n), dim3(512), p.lds, stream, d);
   ICM_CHECK_LAUNCH();
   r.Ca = a->Ca; r.Cb = a->Cb; r.ntaps = ntaps; r.nsplit = nslab; r.nsplit_bias = p.nsplit;
-  r.rows = ntaps <= 8 ? 8 / ntaps : 1;   // a-rows per reduce workgroup (rows x taps x 32 b's fill 256 threads)
-  r.nwblocks = cdiv(a->Ca, r.rows) * cdiv(a->Cb, 32);
+  {
+    const long long CaCb = (long long)a->Ca * a->Cb;
+    bool v4 = ntaps == 1 && (CaCb % 4) == 0;
+    for (int i = 0; i < n; ++i)
+      v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[i].ws) & 15) == 0) && ((reinterpret_cast<uintptr_t>(arr[i].dw) & 15) == 0);
+    r.vec4 = v4 ? 1 : 0;
+    r.nwblocks = (int)((CaCb + (v4 ? 1023 : 255)) / (v4 ? 1024 : 256));
+  }
   bool any_bias = false;
   for (int i = 0; i < n; ++i) any_bias |= arr[i].dbias != nullptr;
   const int rblocks = r.nwblocks + (any_bias ? cdiv(a->Ca, 256) : 0);
