@@ -189,8 +189,11 @@ class Trainer:
         # Weights are packed just in time (Tape.pack), right before the GEMM that reads them: measured on MI355X,
         # packing all 600 MB up front (icm_pack_weights_batch) is 8 % slower end to end -- the packed fragments
         # fall out of the 256 MB Infinity Cache before they are used and the MFMA waves then wait on HBM.
-        for n, _ in f.main:
-            tape.bind_grad(P[n], f.gviews[n], False)
+        # gradients accumulate into the zeroed flat buffer: one 300 MB memset per step replaces the ~150 small
+        # first-writer fills (attention tables, LayerNorm parameter sums, ...) that the stf model otherwise issues
+        f.g.zero_()
+        for n, _ in f.main:   # (the fused EntropyBottleneck backward overwrites its 13 small parameter gradients)
+            tape.bind_grad(P[n], f.gviews[n], not n.startswith("entropy_bottleneck."))
         marks = {}
         if self.is_stf:
             if drops is None:   # stochastic depth, drawn per step like timm's DropPath (stf.py:145)
