@@ -428,3 +428,45 @@ def test_convT_thin_out_vs_torch(shape):
     close(gx, gxr, what="gx")
     close(gw, gwr, what="gw", tol=1e-4)
     close(gb, gbr, what="gb", tol=1e-4)
+
+
+def test_conv_group_shared_input_and_lrp_tail_vs_singles():
+    """conv2d_group with members sharing one input (the fixed support of the late slices) and with the LRP tail fused
+    must equal the same convolutions issued one by one (forward values, input / weight / bias / aux gradients)."""
+    from icm_amd import engine as E
+    from icm_amd.engine import VT
+    d = dev()
+    N, Cin, H, Wd, Cout, n = 2, 40, 8, 8, 32, 5
+    x = U("grp.x", (N, Cin, H, Wd), -1.0, 1.0).to(d)
+    ws = [U(f"grp.w{i}", (Cout, Cin, 3, 3), -0.2, 0.2).to(d) for i in range(n)]
+    bs_ = [U(f"grp.b{i}", (Cout,), -0.3, 0.3).to(d) for i in range(n)]
+    auxs = [U(f"grp.a{i}", (N, Cout, H, Wd), -1.0, 1.0).to(d) for i in range(n)]
+    gs = [U(f"grp.g{i}", (N, Cout, H, Wd), -1.0, 1.0).to(d) for i in range(n)]
+
+    def run(grouped):
+        tape = E.Tape(need_grad=True)
+        xs = x.clone()
+        wl, bl, al = [w.clone() for w in ws], [b.clone() for b in bs_], [a.clone() for a in auxs]
+        if grouped:
+            ys = E.conv2d_group(tape, [VT(xs)] * n, wl, bl, pad=1, outs=[E.new((N, Cout, H, Wd), d) for _ in range(n)],
+                                lrp_auxs=al)
+        else:
+            ys = [E.conv2d(tape, VT(xs), wl[i], bl[i], pad=1, lrp_aux=al[i]) for i in range(n)]
+        for y, g in zip(ys, gs):
+            tape.bind_grad(y, g.clone(), True)
+        tape.backward()
+        torch.cuda.synchronize()
+        return (ys, tape.grad_of(xs), [tape.grad_of(w) for w in wl], [tape.grad_of(b) for b in bl],
+                [tape.grad_of(a) for a in al])
+
+    ya, gxa, gwa, gba, gaa = run(True)
+    yb, gxb, gwb, gbb, gab = run(False)
+    for i in range(n):
+        close(ya[i], yb[i], what=f"y{i}")
+        close(gwa[i], gwb[i], what=f"gw{i}", tol=1e-4)
+        close(gba[i], gbb[i], what=f"gb{i}", tol=1e-4)
+        close(gaa[i], gab[i], what=f"gaux{i}")
+    close(gxa, gxb, what="gx (sum over the members sharing the input)", tol=1e-4)
+    # and against torch for member 0: y = aux + 0.5 * tanh(conv(x))
+    ref = auxs[0].cpu() + 0.5 * torch.tanh(F.conv2d(x.cpu(), ws[0].cpu(), bs_[0].cpu(), padding=1))
+    close(ya[0], ref, what="lrp tail vs torch")
