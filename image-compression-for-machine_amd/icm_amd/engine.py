@@ -25,6 +25,7 @@ from ._lib import (ACT_GELU, ACT_NONE, ACT_SQUARE, EPI_AXPY2, EPI_GDN, EPI_IGDN,
 PEDESTAL = 2.0 ** -36
 import os as _os
 _SKIP_WGRAD = _os.environ.get("ICM_DEBUG_SKIP_WGRAD", "0") == "1"
+PAIR_GATE_BRANCHES = _os.environ.get("ICM_PAIR_GATE_BRANCHES", "1") == "1"
 
 
 def new(shape_or_like, device=None):
@@ -441,7 +442,7 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,
-                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, accum=0):
+                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0):
     n = len(xs)
     arr = (L.ConvArgs * n)()
     for i, a in enumerate(arr):
@@ -456,9 +457,11 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
         a.aux, a.aux_bs = ptr(aux), bs(aux)
         y2 = y2s[i] if y2s is not None else None
         a.y2, a.y2_bs = ptr(y2), bs(y2)
+        res = ress[i] if ress is not None else None
+        a.res, a.res_bs = ptr(res), bs(res)
         a.accum = accum
         if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)
-                  or bs(y2) != bs(y2s[0] if y2s else None)):
+                  or bs(y2) != bs(y2s[0] if y2s else None) or bs(res) != bs(ress[0] if ress else None)):
             raise ValueError("grouped conv: members must share strides")
     check(L.lib().icm_conv_run_grouped(arr, n, tape.st), "conv_run_grouped")
 
@@ -466,12 +469,13 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
 MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_igemm.hip
 
 
-def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None):
+def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, ress=None):
     """The same stride-1 convolution shape applied to several independent (input, weight) pairs in ONE launch:
     cc_mean_transforms[i] || cc_scale_transforms[i] (cnn.py:164-168), and -- because the support of slice i is
     y_hat_slices[:max_support] (cnn.py:161), i.e. the FIRST five slices -- all chains of the slices >= max_support at
     once.  Members may share an input tensor (their input gradients are then summed).  outs / lrp_auxs: write into
-    the given tensors with the LRP tail (cnn.py:175-178) fused.  Returns the list of outputs."""
+    the given tensors with the LRP tail (cnn.py:175-178) fused.  ress: per-member residual VT (identity or virtual
+    GELU) added in the epilogue (ResidualUnit tails of the two gate branches, layers.py:66-71).  Returns the outputs."""
     n = len(xvs)
     if n > MAX_GROUP:
         raise ValueError("conv2d_group: too many members")
@@ -486,9 +490,14 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None):
     ys = list(outs) if outs is not None else [new((N, Cout, OH, OW), x0.device) for _ in range(n)]
     lrp = lrp_auxs is not None
     y2s = [new((N, Cout, OH, OW), x0.device) for _ in range(n)] if lrp else None
+    epi = EPI_LRP if lrp else EPI_NONE
+    if ress is not None:
+        assert not lrp and all(r.act == ress[0].act for r in ress) and ress[0].act in (ACT_NONE, ACT_GELU)
+        epi = EPI_RES_GELU if ress[0].act == ACT_GELU else EPI_RES
     conv_launch_grouped(tape, [v.t for v in xvs], wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
-                        transposed=0, OH=OH, OW=OW, pro_act=act, epi=EPI_LRP if lrp else EPI_NONE,
-                        auxs=list(lrp_auxs) if lrp else None, y2s=y2s)
+                        transposed=0, OH=OH, OW=OW, pro_act=act, epi=epi,
+                        auxs=list(lrp_auxs) if lrp else None, y2s=y2s,
+                        ress=[r.t for r in ress] if ress is not None else None)
     if not tape.need_grad:
         return ys
 
@@ -505,6 +514,9 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None):
                       "lrp_bwd")
                 pre.append(dpre)
             dys = pre
+        if ress is not None:
+            for r, dy in zip(ress, dys):
+                accumulate(tape, r.t, dy, r.t if r.act == ACT_GELU else None)
         for v, w, b, dy in zip(xvs, ws, bs_, dys):
             gw, acc = tape.grad_for_write(w)
             gb_, accb = tape.grad_for_write(b)
@@ -592,6 +604,20 @@ def residual_unit(tape, xv: VT, P, p) -> VT:
     u2 = conv2d(tape, VT(u1, ACT_GELU), P[p + ".conv.2.weight"], P[p + ".conv.2.bias"], pad=1)
     u3 = conv2d(tape, VT(u2, ACT_GELU), P[p + ".conv.4.weight"], P[p + ".conv.4.bias"], res=xv)
     return VT(u3, ACT_GELU)
+
+
+def residual_unit_pair(tape, xa: VT, xb: VT, P, pa, pb):
+    """the same ResidualUnit step of the two independent gate branches (conv_a[j], conv_b[j+1]; layers.py:75-81) as
+    grouped launches: the 4 096-pixel gates (dim 320) fill only half the chip one branch at a time"""
+    u1 = conv2d_group(tape, [xa, xb], [P[pa + ".conv.0.weight"], P[pb + ".conv.0.weight"]],
+                      [P[pa + ".conv.0.bias"], P[pb + ".conv.0.bias"]], pad=0)
+    u2 = conv2d_group(tape, [VT(u1[0], ACT_GELU), VT(u1[1], ACT_GELU)],
+                      [P[pa + ".conv.2.weight"], P[pb + ".conv.2.weight"]],
+                      [P[pa + ".conv.2.bias"], P[pb + ".conv.2.bias"]], pad=1)
+    u3 = conv2d_group(tape, [VT(u2[0], ACT_GELU), VT(u2[1], ACT_GELU)],
+                      [P[pa + ".conv.4.weight"], P[pb + ".conv.4.weight"]],
+                      [P[pa + ".conv.4.bias"], P[pb + ".conv.4.bias"]], pad=0, ress=[xa, xb])
+    return VT(u3[0], ACT_GELU), VT(u3[1], ACT_GELU)
 
 
 def window_msa_core(tape, qkv, table, C_, heads, ws, shift) -> torch.Tensor:
@@ -734,11 +760,15 @@ def patch_split(tape, x, P, p) -> torch.Tensor:
 def attention_gate(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
     """Win_noShift_Attention.forward (layers/layers.py:83-89): a*sigmoid(b) + x."""
     a = VT(x)
-    for i in range(3):
-        a = residual_unit(tape, a, P, f"{p}.conv_a.{i}")
     b = VT(window_attention(tape, x, P, p + ".conv_b.0", heads, ws, shift))
-    for i in (1, 2, 3):
-        b = residual_unit(tape, b, P, f"{p}.conv_b.{i}")
+    if PAIR_GATE_BRANCHES:
+        for i in range(3):   # conv_a[i] and conv_b[i + 1] are independent and shape-identical
+            a, b = residual_unit_pair(tape, a, b, P, f"{p}.conv_a.{i}", f"{p}.conv_b.{i + 1}")
+    else:
+        for i in range(3):
+            a = residual_unit(tape, a, P, f"{p}.conv_a.{i}")
+        for i in (1, 2, 3):
+            b = residual_unit(tape, b, P, f"{p}.conv_b.{i}")
     b4 = conv2d(tape, b, P[p + ".conv_b.4.weight"], P[p + ".conv_b.4.bias"])
     out = new(x)
     xc = x if x.is_contiguous() else x.contiguous()
