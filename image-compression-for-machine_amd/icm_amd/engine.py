@@ -442,7 +442,7 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,
-                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0):
+                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0, ps=0):
     n = len(xs)
     arr = (L.ConvArgs * n)()
     for i, a in enumerate(arr):
@@ -459,7 +459,7 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
         a.y2, a.y2_bs = ptr(y2), bs(y2)
         res = ress[i] if ress is not None else None
         a.res, a.res_bs = ptr(res), bs(res)
-        a.accum = accum
+        a.accum, a.pixel_shuffle = accum, ps
         if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)
                   or bs(y2) != bs(y2s[0] if y2s else None) or bs(res) != bs(ress[0] if ress else None)):
             raise ValueError("grouped conv: members must share strides")
@@ -469,7 +469,7 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
 MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_igemm.hip
 
 
-def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, ress=None):
+def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, ress=None, pixel_shuffle=0):
     """The same stride-1 convolution shape applied to several independent (input, weight) pairs in ONE launch:
     cc_mean_transforms[i] || cc_scale_transforms[i] (cnn.py:164-168), and -- because the support of slice i is
     y_hat_slices[:max_support] (cnn.py:161), i.e. the FIRST five slices -- all chains of the slices >= max_support at
@@ -487,8 +487,11 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
         raise ValueError("conv2d_group: channel mismatch")
     OH, OW = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
     wps = [tape.pack(w, Cout, Cin, KH, KW, 1, 0, 1, pad) for w in ws]
-    ys = list(outs) if outs is not None else [new((N, Cout, OH, OW), x0.device) for _ in range(n)]
+    oshape = (N, Cout // 4, OH * 2, OW * 2) if pixel_shuffle == 2 else (N, Cout, OH, OW)
+    ys = list(outs) if outs is not None else [new(oshape, x0.device) for _ in range(n)]
+    assert all(tuple(y.shape) == oshape for y in ys)
     lrp = lrp_auxs is not None
+    assert not (pixel_shuffle and (lrp or ress is not None))
     y2s = [new((N, Cout, OH, OW), x0.device) for _ in range(n)] if lrp else None
     epi = EPI_LRP if lrp else EPI_NONE
     if ress is not None:
@@ -497,7 +500,7 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
     conv_launch_grouped(tape, [v.t for v in xvs], wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
                         transposed=0, OH=OH, OW=OW, pro_act=act, epi=epi,
                         auxs=list(lrp_auxs) if lrp else None, y2s=y2s,
-                        ress=[r.t for r in ress] if ress is not None else None)
+                        ress=[r.t for r in ress] if ress is not None else None, ps=pixel_shuffle)
     if not tape.need_grad:
         return ys
 
@@ -505,6 +508,14 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
         dys = [tape.grad_of(y) for y in ys]
         if any(d is None for d in dys):
             raise RuntimeError("conv2d_group: every member needs a gradient")
+        if pixel_shuffle == 2:   # gradient of the fused PixelShuffle store
+            un = []
+            for dy in dys:
+                du = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x0.device)
+                dyc = dy if dy.is_contiguous() else dy.contiguous()
+                check(L.lib().icm_pixel_unshuffle2(ptr(dyc), ptr(du), N, Cout // 4, OH, OW, tape.st), "pixel_unshuffle2")
+                un.append(du)
+            dys = un
         if lrp:
             pre = []
             for dy, aux, y2 in zip(dys, lrp_auxs, y2s):

@@ -88,6 +88,18 @@ def _h_s(tape, P, p, z_hat, out):
     return E.conv2d(tape, VT(u, ACT_GELU), P[p + ".8.weight"], P[p + ".8.bias"], pad=1, out=out)
 
 
+def _h_s_pair(tape, P, p1, p2, z_hat, out1, out2):
+    """h_scale_s and h_mean_s (cnn.py:66-88) are independent and shape-identical: each of their five convolutions
+    (two with the PixelShuffle store) runs as one grouped launch"""
+    xv = [VT(z_hat), VT(z_hat)]
+    for name, ps, last in ((".0", 0, False), (".2.0", 2, False), (".4", 0, False), (".6.0", 2, False), (".8", 0, True)):
+        ts = E.conv2d_group(tape, xv, [P[p1 + name + ".weight"], P[p2 + name + ".weight"]],
+                            [P[p1 + name + ".bias"], P[p2 + name + ".bias"]], pad=1, pixel_shuffle=ps,
+                            outs=[out1, out2] if last else None)
+        xv = [VT(ts[0], ACT_GELU), VT(ts[1], ACT_GELU)]
+    return ts
+
+
 def _copy_op(tape, src, dst):
     """dst = src (cat/chunk plumbing) with gradient routed back"""
     E.copy_into(tape, src, dst)
@@ -138,8 +150,7 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
             tape.bind_grad(SS[:, sl], dSS[:, sl], True)
     if (h % 4) or (w % 4):
         raise ValueError("hyper-synthesis output does not match the latent size (input must be a multiple of 64)")
-    _h_s(tape, P, "h_scale_s", z_hat, SS[:, :M])
-    _h_s(tape, P, "h_mean_s", z_hat, MS[:, :M])
+    _h_s_pair(tape, P, "h_scale_s", "h_mean_s", z_hat, SS[:, :M], MS[:, :M])
     Y_hat = E.new((N, M, h, w), dev)
     Y_lik = E.new((N, M, h, w), dev)
     if need:

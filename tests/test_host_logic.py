@@ -123,8 +123,8 @@ def test_wacnn_tape_plumbing_dry_run(dry):
     # grouped launches (forward and dgrad): the mean/scale pair of the 5 serial slices (5 x 5 convs), then the 10
     # mean/scale chains and the 5 lrp chains of the independent tail slices 5..9 as one chain each (5 + 5 layers);
     # the 263 weight gradients are deferred and issued in batches of identical geometry
-    # plus the 4 gates: 3 ResidualUnit steps x 3 convs of the two branches paired
-    assert dry.calls["icm_conv_run"] > 100 and dry.calls["icm_conv_run_grouped"] == 2 * (25 + 5 + 5 + 4 * 9)
+    # plus the 4 gates (3 ResidualUnit steps x 3 convs of the two branches paired) and the h_scale_s / h_mean_s pair
+    assert dry.calls["icm_conv_run"] > 100 and dry.calls["icm_conv_run_grouped"] == 2 * (25 + 5 + 5 + 4 * 9 + 5)
     assert 20 <= dry.calls["icm_conv_wgrad_grouped"] <= 80 and dry.calls.get("icm_conv_wgrad", 0) == 6
     assert dry.calls["icm_gc_likelihood_ste_fwd"] == 10 and dry.calls["icm_gc_likelihood_ste_bwd"] == 10
     assert dry.calls["icm_winattn_fwd"] == 4 and dry.calls["icm_winattn_bwd"] == 4
