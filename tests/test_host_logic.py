@@ -179,3 +179,25 @@ def test_stf_rejects_non_default_architecture():
     from icm_amd.models import SymmetricalTransFormer
     with pytest.raises(NotImplementedError):
         SymmetricalTransFormer(embed_dim=96)
+
+
+@pytest.mark.parametrize("name", ["cnn", "stf"])
+def test_trainer_step_plumbing_dry_run(dry, name):
+    """two native training steps with launches stubbed: bucket markers, deferred weight gradients, the recorded
+    weight-packing sequence (step 1) and its windowed replay (step 2), clip + 2 x Adam + aux step all get issued"""
+    from icm_amd.zoo import models
+    from icm_amd.trainer import Trainer, BUCKETS
+    torch.manual_seed(0)
+    tr = Trainer(models[name](), device="cpu")
+    assert tr.side is None and len(tr.flat.bucket_ranges) == len(BUCKETS)
+    x = torch.rand(2, 3, 64, 64)
+    s1 = tr.step(x)
+    assert s1.shape == (8,) and tr._pack_seq is not None and len(tr._pack_seq) > 100
+    single_packs = dry.calls.get("icm_pack_weights", 0)
+    assert single_packs == len(tr._pack_seq) and "icm_pack_weights_batch" not in dry.calls
+    tr.step(x)
+    # step 2 replays the sequence in windows of 24: no single packs any more
+    assert dry.calls.get("icm_pack_weights", 0) == single_packs
+    assert dry.calls["icm_pack_weights_batch"] == -(-len(tr._pack_seq) // 24)
+    assert dry.calls["icm_adam_step"] == 4 and dry.calls["icm_grad_sqnorm"] == 2 and dry.calls["icm_eb_aux_loss"] == 2
+    assert dry.calls["icm_rd_loss_fwd"] == 2 and dry.calls["icm_conv_wgrad_grouped"] > 40
