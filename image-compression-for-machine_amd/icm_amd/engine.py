@@ -52,13 +52,16 @@ def _key(t: torch.Tensor):
 
 
 class Tape:
-    def __init__(self, need_grad: bool = True):
+    def __init__(self, need_grad: bool = True, packed_cache: Optional[dict] = None):
+        """packed_cache: a dict kept by the caller across forward calls with CONSTANT weights (inference): the packed
+        MFMA-order weight copies are then produced once instead of once per call.  The cache key holds the tensor's
+        autograd version, which in-place HIP updates (icm_adam_step) do not bump -- never share a cache with training."""
         self.need_grad = need_grad
         self.bw: List[Callable[[], None]] = []
         self.grads: Dict[tuple, torch.Tensor] = {}
         self.ready = set()
         self.stopped = set()
-        self._packed: Dict[tuple, torch.Tensor] = {}
+        self._packed: Dict[tuple, torch.Tensor] = packed_cache if packed_cache is not None else {}
         self._ws: Optional[torch.Tensor] = None
         self.wjobs: list = []
         self.pack_log = None      # when a list: records (w, args) of every cache miss (the trainer's packing plan)
