@@ -60,9 +60,9 @@ template <int EPI, int half>
 __device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot, int h,
                                              int n, int oy, int ox, bool pvalid) {
   const int plane = d.OHf * d.OWf;
-  constexpr bool kRes = EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU;
+  constexpr bool kRes = EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU || EPI == ICM_EPI_RES_MUL_DGELU;
   constexpr bool kAux = EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN || EPI == ICM_EPI_MUL_DGELU ||
-                        EPI == ICM_EPI_AXPY2 || EPI == ICM_EPI_LRP;
+                        EPI == ICM_EPI_AXPY2 || EPI == ICM_EPI_LRP || EPI == ICM_EPI_RES_MUL_DGELU;
   float* yb = P.y + n * d.y_bs;
   const float* resb = kRes ? P.res + n * d.res_bs : nullptr;
   const float* auxb = kAux ? P.aux + n * d.aux_bs : nullptr;
@@ -97,6 +97,7 @@ __device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& 
         v[q] = av[q] * (EPI == ICM_EPI_GDN ? rsqrtf(v[q]) : sqrtf(v[q]));
       }
       if constexpr (EPI == ICM_EPI_MUL_DGELU) v[q] *= dgelu_f(av[q]);
+      if constexpr (EPI == ICM_EPI_RES_MUL_DGELU) v[q] = (v[q] + rv[q]) * dgelu_f(av[q]);
       if constexpr (EPI == ICM_EPI_AXPY2) v[q] = rv[q] + 2.0f * av[q] * v[q];
       if constexpr (EPI == ICM_EPI_LRP) {
         const float t = tanhf(v[q]);
@@ -354,6 +355,9 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
     case ICM_EPI_MUL_DGELU: epilogue_all<ICM_EPI_MUL_DGELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
     case ICM_EPI_AXPY2: epilogue_all<ICM_EPI_AXPY2, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
     case ICM_EPI_LRP: epilogue_all<ICM_EPI_LRP, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+    case ICM_EPI_RES_MUL_DGELU:
+      epilogue_all<ICM_EPI_RES_MUL_DGELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0);
+      break;
     default: epilogue_all<ICM_EPI_NONE, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
   }
 }
@@ -679,9 +683,9 @@ static int validate(const icm_conv_args& a) {
     if (a.OH != (a.H + 2 * a.pad - a.KH) / a.stride + 1 || a.OW != (a.W + 2 * a.pad - a.KW) / a.stride + 1)
       return ICM_ERR_ARG;
   }
-  if ((a.epi == ICM_EPI_RES || a.epi == ICM_EPI_RES_GELU) && !a.res) return ICM_ERR_ARG;
+  if ((a.epi == ICM_EPI_RES || a.epi == ICM_EPI_RES_GELU || a.epi == ICM_EPI_RES_MUL_DGELU) && !a.res) return ICM_ERR_ARG;
   if ((a.epi == ICM_EPI_GDN || a.epi == ICM_EPI_IGDN || a.epi == ICM_EPI_MUL_DGELU || a.epi == ICM_EPI_LRP ||
-       a.epi == ICM_EPI_AXPY2) && !a.aux)
+       a.epi == ICM_EPI_AXPY2 || a.epi == ICM_EPI_RES_MUL_DGELU) && !a.aux)
     return ICM_ERR_ARG;
   if (a.epi == ICM_EPI_AXPY2 && !a.aux2) return ICM_ERR_ARG;
   if (((long long)a.N * a.x_bs + 8LL * a.H * a.W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32

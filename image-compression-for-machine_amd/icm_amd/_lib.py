@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICM_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libicm_hip.so"))
 
 ACT_NONE, ACT_GELU, ACT_SQUARE = 0, 1, 2
-EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_GDN, EPI_IGDN, EPI_MUL_DGELU, EPI_AXPY2, EPI_LRP = range(8)
+EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_GDN, EPI_IGDN, EPI_MUL_DGELU, EPI_AXPY2, EPI_LRP, EPI_RES_MUL_DGELU = range(9)
 
 _f = C.POINTER(C.c_float)
 i64, i32, f32, vp = C.c_int64, C.c_int, C.c_float, C.c_void_p

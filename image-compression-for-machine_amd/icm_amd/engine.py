@@ -20,7 +20,7 @@ import torch
 
 from . import _lib as L
 from ._lib import (ACT_GELU, ACT_NONE, ACT_SQUARE, EPI_AXPY2, EPI_GDN, EPI_IGDN, EPI_LRP, EPI_MUL_DGELU, EPI_NONE,
-                   EPI_RES, EPI_RES_GELU, bs, check, ptr)
+                   EPI_RES, EPI_RES_GELU, EPI_RES_MUL_DGELU, bs, check, ptr)
 
 PEDESTAL = 2.0 ** -36
 import os as _os
@@ -73,6 +73,7 @@ class Tape:
         self._flushed: list = []  # keeps side-stream operands alive until the streams are joined
         self.progress_every = 0
         self.min_jobs = 8
+        self._pending_res: Dict[tuple, tuple] = {}   # key(t) -> (t, dy, gelu): identity-path gradient not yet added
         self.hold_wgrads = False  # True: queue weight gradients without periodic flushes (the slice-chain section
         #                           batches its 150 small problems by geometry at the section end)
         self.st = L.stream()
@@ -92,8 +93,38 @@ class Tape:
         else:
             self.ready.discard(k)
 
+    # ---- identity-path gradients of residual adds (ResidualUnit: out = conv(...) + x): instead of a separate
+    # elementwise pass  d(x) += dy * act'(x)  the term rides on the epilogue of the dgrad that writes d(x) next
+    # (the unit's first convolution consumes the same x with the same virtual activation)
+    def defer_res_grad(self, t, dy, gelu: bool):
+        if not self.wants(t):
+            return
+        k = _key(t)
+        if k in self._pending_res:
+            self._flush_res(k)
+        self._pending_res[k] = (t, dy, gelu)
+
+    def take_res_grad(self, t, gelu: bool):
+        """the pending identity-path gradient of t if its activation matches the caller's dgrad epilogue, else None
+        (a mismatching one is applied with a separate pass)"""
+        k = _key(t)
+        p = self._pending_res.get(k)
+        if p is None:
+            return None
+        if p[2] != gelu:
+            self._flush_res(k)
+            return None
+        del self._pending_res[k]
+        return p[1]
+
+    def _flush_res(self, k):
+        t, dy, gelu = self._pending_res.pop(k)
+        accumulate(self, t, dy, t if gelu else None)
+
     def grad_for_write(self, t) -> Tuple[torch.Tensor, int]:
         k = _key(t)
+        if k in self._pending_res:
+            self._flush_res(k)
         g = self.grads.get(k)
         if g is None:
             g = torch.empty(t.shape, dtype=torch.float32, device=t.device)
@@ -104,6 +135,8 @@ class Tape:
 
     def grad_of(self, t) -> Optional[torch.Tensor]:
         k = _key(t)
+        if k in self._pending_res:
+            self._flush_res(k)
         return self.grads.get(k) if k in self.ready else None
 
     def backward(self):
@@ -115,6 +148,8 @@ class Tape:
                     and not self.hold_wgrads):
                 flush_wgrads(self)
         self.bw = []
+        for k in list(self._pending_res):
+            self._flush_res(k)
         flush_wgrads(self)
         self.join_side()
 
@@ -352,7 +387,7 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             check(L.lib().icm_pixel_unshuffle2(ptr(dy), ptr(du), N, Cout // 4, OH, OW, tape.st), "pixel_unshuffle2")
             dy = du
         if res is not None:
-            accumulate(tape, res.t, dy, res.t if res.act == ACT_GELU else None)
+            tape.defer_res_grad(res.t, dy, res.act == ACT_GELU)
         want_b = b is not None and tape.wants(b)
         fuse_b = want_b and not transposed and tape.wants(w)   # bias grad rides on the wgrad loaders
         if want_b and not fuse_b:
@@ -368,21 +403,22 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
                 wgrad_defer(tape, x, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=act,
                             accum=acc)
         if tape.wants(x):
+            rg = tape.take_res_grad(x, act == ACT_GELU) if act in (ACT_GELU, ACT_NONE) else None
             gx, acc = tape.grad_for_write(x)
             if act == ACT_GELU:
-                epi_b, aux_b = EPI_MUL_DGELU, x
+                epi_b, aux_b = (EPI_RES_MUL_DGELU if rg is not None else EPI_MUL_DGELU), x
             elif act == ACT_NONE:
-                epi_b, aux_b = EPI_NONE, None
+                epi_b, aux_b = (EPI_RES if rg is not None else EPI_NONE), None
             else:
                 raise NotImplementedError("dgrad through this virtual activation")
             if not transposed:   # conv dgrad = scatter with W ([K=Cout][M=Cin])
                 wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
-                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, accum=acc)
+                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc)
             else:                # convT dgrad = gather with Wt ([M=Cin][K=Cout])
                 wpb = tape.pack(w4, Cin, Cout, KH, KW, 1, 0, stride, pad)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
-                            transposed=0, OH=H, OW=W, epi=epi_b, aux=aux_b, accum=acc)
+                            transposed=0, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc)
 
     tape.bw.append(bwd)
     return y
@@ -530,7 +566,7 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
             dys = pre
         if ress is not None:
             for r, dy in zip(ress, dys):
-                accumulate(tape, r.t, dy, r.t if r.act == ACT_GELU else None)
+                tape.defer_res_grad(r.t, dy, r.act == ACT_GELU)
         for v, w, b, dy in zip(xvs, ws, bs_, dys):
             gw, acc = tape.grad_for_write(w)
             gb_, accb = tape.grad_for_write(b)
@@ -541,21 +577,33 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
         # written (or accumulated) in place.
         keys = [_key(v.t) for v in xvs]
         shared = len(set(keys)) < n
+        rgs = None
+        if not shared and act in (ACT_GELU, ACT_NONE) and all(k in tape._pending_res and
+                                                              tape._pending_res[k][2] == (act == ACT_GELU) for k in keys):
+            rgs = [tape.take_res_grad(v.t, act == ACT_GELU) for v in xvs]   # identity-path terms ride on this dgrad
         if not shared:
             gxs, accs = [], []
             for v in xvs:
                 gx, ax = tape.grad_for_write(v.t)
                 gxs.append(gx)
                 accs.append(ax)
-            assert len(set(accs)) == 1
+            if len(set(accs)) > 1:   # one launch, one accumulate flag: zero the buffers that nobody has written yet
+                for gx, ax in zip(gxs, accs):
+                    if not ax:
+                        gx.zero_()
+                accs = [1] * n
             acc0 = accs[0]
         else:
             gxs = [torch.empty((N, Cin, H, W), dtype=torch.float32, device=x0.device) for _ in range(n)]
             acc0 = 0
         wpb = [tape.pack(w, Cin, Cout, KH, KW, 0, 1, 1, pad) for w in ws]
+        if act == ACT_GELU:
+            epi_b = EPI_RES_MUL_DGELU if rgs is not None else EPI_MUL_DGELU
+        else:
+            epi_b = EPI_RES if rgs is not None else EPI_NONE
         conv_launch_grouped(tape, dys, wpb, None, gxs, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=1, pad=pad,
-                            transposed=1, OH=H, OW=W, epi=EPI_MUL_DGELU if act == ACT_GELU else EPI_NONE,
-                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, accum=acc0)
+                            transposed=1, OH=H, OW=W, epi=epi_b,
+                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, ress=rgs, accum=acc0)
         if shared:
             for v, g in zip(xvs, gxs):
                 accumulate(tape, v.t, g)

@@ -40,6 +40,7 @@ extern "C" {
 #define ICM_EPI_MUL_DGELU 5   /* y = acc * gelu'(aux)              (backward through a virtual GELU) */
 #define ICM_EPI_AXPY2 6       /* y = aux2 + 2*aux*acc              (GDN backward dx) */
 #define ICM_EPI_LRP 7         /* y = aux + 0.5*tanh(acc + bias); y2 = tanh(...)  (cnn.py:175-178) */
+#define ICM_EPI_RES_MUL_DGELU 8 /* y = (acc + res) * gelu'(aux)   (dgrad into a ResidualUnit input: conv path + identity path) */
 
 const char* icm_strerror(int code);
 int icm_version(void);
