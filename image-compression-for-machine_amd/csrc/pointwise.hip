@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            long long dxbs, int N, int C, int HW, int accum) {
+                                                            long long dxbs, int N, int C, int HW, int accum,
+                                                            const float* __restrict__ extra, long long ebs) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long long total = (long long)N * HW;
@@ -222,9 +223,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     __syncthreads();
     if (valid) {
       float* dp = dx + n * dxbs + p;
+      const float* ep = extra ? extra + n * ebs + p : nullptr;
       for (int c = cs; c < C; c += 4) {
         const float xh = (xp[(long long)c * HW] - m) * r;
         float v = r * (gp[(long long)c * HW] * gamma[c] - s1 - xh * s2);
+        if (ep) v += ep[(long long)c * HW];   // identity-path gradient of the residual add around this LayerNorm
         if (accum) v += dp[(long long)c * HW];
         dp[(long long)c * HW] = v;
       }
@@ -522,12 +525,14 @@ int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const fl
 }
 int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t dx_bs, float* dgamma, float* dbeta,
-                      int N, int C, int HW, int accum_dx, int accum_params, void* stream) {
+                      int N, int C, int HW, int accum_dx, int accum_params, const float* dx_extra, int64_t dx_extra_bs,
+                      void* stream) {
   if (!x || !dy || !gamma || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   if (dx) {
     const long long tiles = ((long long)N * HW + 63) / 64;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)std::min<long long>(tiles, 256 * 16)), dim3(256), 0, ST, x,
-                       (long long)x_bs, dy, (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx);
+                       (long long)x_bs, dy, (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx,
+                       dx_extra, (long long)dx_extra_bs);
     ICM_CHECK_LAUNCH();
   }
   if (dgamma && dbeta) {

@@ -109,7 +109,7 @@ def lib():
         L.icm_lrp_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
         L.icm_pixel_unshuffle2.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.icm_layernorm_fwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, i32, f32, vp]
-        L.icm_layernorm_bwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp]
+        L.icm_layernorm_bwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]
         L.icm_space_to_depth2.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.icm_residual_scale.argtypes = [vp, vp, vp, vp, i32, i64, vp]
         L.icm_im2col.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

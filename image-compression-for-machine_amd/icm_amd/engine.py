@@ -742,10 +742,13 @@ def layernorm(tape, x, gamma, beta) -> torch.Tensor:
                 gg, ap = tape.grad_for_write(gamma)
                 gb_, ap2 = tape.grad_for_write(beta)
                 assert ap == ap2
+            rg = None
             if tape.wants(x):
+                rg = tape.take_res_grad(x, False)   # x + f(LN(x)): the identity-path term rides on this pass
                 dx, ax = tape.grad_for_write(x)
             check(L.lib().icm_layernorm_bwd(ptr(x), bs(x), ptr(dy), bs(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
-                                            bs(dx), ptr(gg), ptr(gb_), N, Cc, HW, ax, ap, tape.st), "layernorm_bwd")
+                                            bs(dx), ptr(gg), ptr(gb_), N, Cc, HW, ax, ap, ptr(rg), bs(rg), tape.st),
+                  "layernorm_bwd")
         tape.bw.append(bwd)
     return y
 
@@ -762,7 +765,7 @@ def residual_scale(tape, shortcut, branch, scale) -> torch.Tensor:
             g = tape.grad_of(out)
             if g is None:
                 return
-            accumulate(tape, shortcut, g)
+            tape.defer_res_grad(shortcut, g, False)   # rides on the LayerNorm backward that writes d(shortcut) next
             db, acc = tape.grad_for_write(branch)
             assert acc == 0 and db.is_contiguous()
             check(L.lib().icm_residual_scale(0, ptr(g), ptr(scale), ptr(db), N, per, tape.st), "residual_scale_bwd")

@@ -155,9 +155,12 @@ int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_b
  * mean/rstd [N*HW] are saved for backward (may be NULL in inference) */
 int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const float* beta, float* y, int64_t y_bs,
                       float* mean, float* rstd, int N, int C, int HW, float eps, void* stream);
+/* dx_extra (optional, [N,C,HW] with its own batch stride): added to dx -- the identity-path gradient of the residual
+ * add around the norm (x + f(LN(x)), stf.py:190-191) without a separate elementwise pass */
 int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t dx_bs, float* dgamma, float* dbeta,
-                      int N, int C, int HW, int accum_dx, int accum_params, void* stream);
+                      int N, int C, int HW, int accum_dx, int accum_params, const float* dx_extra, int64_t dx_extra_bs,
+                      void* stream);
 /* PatchMerging's 2x2 gather (stf.py:224-228): dst[n][k*C+c][y][x] = src[n][c][2y+(k&1)][2x+(k>>1)]; inverse=1 scatters
  * a [N,4C,H/2,W/2] gradient back into [N,C,H,W] */
 int icm_space_to_depth2(const float* src, float* dst, int N, int C, int H, int W, int inverse, int accum, void* stream);
