@@ -163,7 +163,15 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
   const ConvPtrs P = d.g[blockIdx.y];
   const PatchGeom& pg = d.pg;
 
-  int bid = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so hardware id b
+  // runs on XCD b % 8.  Give every XCD a CONTIGUOUS run of logical tiles: the co-blocks of one pixel tile and the
+  // vertically adjacent tiles (which share most of their halo rows) then meet in the same L2.
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
   const int cb = bid % d.ncb;
   int pt = bid / d.ncb;
   const int tx_i = pt % d.tiles_x;

@@ -55,7 +55,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   const bool loader = wave >= 4;
   const WgPtrs G = d.g[blockIdx.y];
 
-  int bid = blockIdx.x;
+  // XCD-aware order (see conv_igemm.hip): hardware id b runs on XCD b % 8; every XCD gets a contiguous run of logical
+  // workgroups, so the (a-tile, b-tile, tap-group) workgroups of one pixel split read their pixels through one L2
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
   const int at = bid % d.natile; bid /= d.natile;
   const int bt = bid % d.nbtile; bid /= d.nbtile;
   const int tg = bid % d.ngroups;
