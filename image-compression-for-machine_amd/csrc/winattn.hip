@@ -100,7 +100,14 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const WaDesc d) {
   float* Ksh = smem + (wave * G + grp) * (2 * T * HD + T * TS);
   float* Vsh = Ksh + T * HD;
   float* Ssh = Vsh + T * HD;
-  int bid = blockIdx.x;
+  // XCD-aware window order: hardware id b runs on XCD b % 8; a contiguous run of windows per XCD lets horizontally
+  // adjacent windows (which share every 128-B line of a 4- or 8-pixel-wide row segment) meet in one L2
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
   const int wx = bid % d.nwx; bid /= d.nwx;
   const int wy = bid % d.nwy;
   const int n = bid / d.nwy;
@@ -176,7 +183,14 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
   float* Ssh = Gsh + T * HD;   // P then dS
   float* Qsh = Vsh;            // scaled q, written after the dq phase
   float* Bsh = Gsh;            // per-head table gradient, zeroed after the dV phase
-  int bid = blockIdx.x;
+  // XCD-aware window order: hardware id b runs on XCD b % 8; a contiguous run of windows per XCD lets horizontally
+  // adjacent windows (which share every 128-B line of a 4- or 8-pixel-wide row segment) meet in one L2
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
   const int wx = bid % d.nwx; bid /= d.nwx;
   const int wy = bid % d.nwy;
   const int n = bid / d.nwy;
