@@ -234,6 +234,108 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
   }
 }
+// Register-cached variants for C = 4 * CPT <= 192 (stf levels 0-2 and patch_embed): every thread keeps its CPT channel
+// values of x (and dy) in registers, so each tensor is read from HBM once instead of three times.
+template <int CPT>
+__global__ __launch_bounds__(256) void layernorm_fwd_cached_kernel(const float* __restrict__ x, long long xbs,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   float* __restrict__ y, long long ybs,
+                                                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                                                   int N, int HW, float eps) {
+  constexpr int C = 4 * CPT;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long total = (long long)N * HW;
+  const long long ntiles = (total + 63) / 64;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long i = tile * 64 + lane;
+    const bool valid = i < total;
+    const int n = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (long long)n * HW) : 0;
+    const float* xp = x + n * xbs + p;
+    float xv[CPT];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      xv[k] = valid ? xp[(long long)(cs + 4 * k) * HW] : 0.0f;
+      s += xv[k];
+    }
+    red[cs][lane] = s;
+    __syncthreads();
+    const float m = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)C;
+    __syncthreads();
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const float dd = xv[k] - m;
+      v += dd * dd;
+    }
+    red[cs][lane] = v;
+    __syncthreads();
+    const float r = rsqrtf(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)C + eps);
+    __syncthreads();
+    if (valid) {
+      if (cs == 0 && mean) { mean[i] = m; rstd[i] = r; }
+      float* yp = y + n * ybs + p;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        const int c = cs + 4 * k;
+        yp[(long long)c * HW] = (xv[k] - m) * r * gamma[c] + beta[c];
+      }
+    }
+  }
+}
+template <int CPT>
+__global__ __launch_bounds__(256) void layernorm_bwd_cached_kernel(const float* __restrict__ x, long long xbs,
+                                                                   const float* __restrict__ dy, long long dbs,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd,
+                                                                   float* __restrict__ dx, long long dxbs, int N,
+                                                                   int HW, int accum, const float* __restrict__ extra,
+                                                                   long long ebs) {
+  constexpr int C = 4 * CPT;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long long total = (long long)N * HW;
+  const long long ntiles = (total + 63) / 64;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long i = tile * 64 + lane;
+    const bool valid = i < total;
+    const int n = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (long long)n * HW) : 0;
+    const float* xp = x + n * xbs + p;
+    const float* gp = dy + n * dbs + p;
+    const float m = valid ? mean[i] : 0.0f, r = valid ? rstd[i] : 0.0f;
+    float xh[CPT], gg[CPT];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int c = cs + 4 * k;
+      xh[k] = valid ? (xp[(long long)c * HW] - m) * r : 0.0f;
+      gg[k] = valid ? gp[(long long)c * HW] * gamma[c] : 0.0f;
+      s1 += gg[k];
+      s2 += gg[k] * xh[k];
+    }
+    red[0][cs][lane] = s1;
+    red[1][cs][lane] = s2;
+    __syncthreads();
+    s1 = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
+    s2 = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
+    __syncthreads();
+    if (valid) {
+      float* dp = dx + n * dxbs + p;
+      const float* ep = extra ? extra + n * ebs + p : nullptr;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) {
+        const int c = cs + 4 * k;
+        float v = r * (gg[k] - s1 - xh[k] * s2);
+        if (ep) v += ep[(long long)c * HW];
+        if (accum) v += dp[(long long)c * HW];
+        dp[(long long)c * HW] = v;
+      }
+    }
+  }
+}
 // dgamma[c] += sum_{n,p} dy * xhat ; dbeta[c] += sum dy.  grid (C, S): workgroup (c, s) reduces pixel chunk s of
 // channel c and adds its partial with one float atomic per output (outputs zeroed first unless accumulating)
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, long long xbs,
@@ -518,8 +620,17 @@ int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const fl
                       float* mean, float* rstd, int N, int C, int HW, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   const long long tiles = ((long long)N * HW + 63) / 64;
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)std::min<long long>(tiles, 256 * 16)), dim3(256), 0, ST, x,
-                     (long long)x_bs, gamma, beta, y, (long long)y_bs, mean, rstd, N, C, HW, eps);
+  const dim3 grid((unsigned)std::min<long long>(tiles, 256 * 16));
+#define ICM_LN_FWD(CPT)                                                                                              \
+  hipLaunchKernelGGL(layernorm_fwd_cached_kernel<CPT>, grid, dim3(256), 0, ST, x, (long long)x_bs, gamma, beta, y,   \
+                     (long long)y_bs, mean, rstd, N, HW, eps)
+  if (C == 48) ICM_LN_FWD(12);
+  else if (C == 96) ICM_LN_FWD(24);
+  else if (C == 192) ICM_LN_FWD(48);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel, grid, dim3(256), 0, ST, x, (long long)x_bs, gamma, beta, y, (long long)y_bs,
+                       mean, rstd, N, C, HW, eps);
+#undef ICM_LN_FWD
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
@@ -530,9 +641,18 @@ int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
   if (!x || !dy || !gamma || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   if (dx) {
     const long long tiles = ((long long)N * HW + 63) / 64;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)std::min<long long>(tiles, 256 * 16)), dim3(256), 0, ST, x,
-                       (long long)x_bs, dy, (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx,
-                       dx_extra, (long long)dx_extra_bs);
+    const dim3 grid((unsigned)std::min<long long>(tiles, 256 * 16));
+#define ICM_LN_BWD(CPT)                                                                                              \
+  hipLaunchKernelGGL(layernorm_bwd_cached_kernel<CPT>, grid, dim3(256), 0, ST, x, (long long)x_bs, dy,               \
+                     (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, HW, accum_dx, dx_extra,           \
+                     (long long)dx_extra_bs)
+    if (C == 48) ICM_LN_BWD(12);
+    else if (C == 96) ICM_LN_BWD(24);
+    else if (C == 192) ICM_LN_BWD(48);
+    else
+      hipLaunchKernelGGL(layernorm_bwd_kernel, grid, dim3(256), 0, ST, x, (long long)x_bs, dy, (long long)dy_bs, gamma,
+                         mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx, dx_extra, (long long)dx_extra_bs);
+#undef ICM_LN_BWD
     ICM_CHECK_LAUNCH();
   }
   if (dgamma && dbeta) {
