@@ -1,15 +1,28 @@
 #!/usr/bin/env python
 """Headline benchmark: images/s of the `cnn` (WACNN) training step on synthetic 256x256 batches.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the
+driver's way: WORLD_SIZE is set) or started plainly, in which case this script starts that launcher itself as a
+child process BEFORE anything touches the GPU and exits with its code.
 
 One step = the reference training iteration (train.py:188-214): forward, R-D loss (lambda=0.0067),
 backward, clip_grad_norm_(1.0), Adam on the 75.2 M parameters, aux loss + Adam on the quantiles; batch 16
-per GPU (BASELINE.json configs[1]; configs[2] = 8 GPUs x 16).  Prints ONE JSON line.
+per GPU (BASELINE.json configs[1]; configs[2] = 8 GPUs x 16).  Prints ONE JSON line:
+
+  value / ms_per_step   whole-job images/s over the timed region (barrier + synchronize on both sides, max over ranks)
+  roofline_step         the whole step against the f32-MFMA roofline (206.6 GFLOP / image)
+  roofline              the kernel FAMILY (implicit-GEMM conv = forward + input gradients | weight gradients) that is
+                        furthest below the roofline among those with >= 15 % of the step's kernel time: algorithmic
+                        FLOP of its launches / their HIP-event time, measured live in one extra, serialised step
+  roofline_shapes       the same per launch shape (top shapes by time share)
+  cpu_baseline          the CPU oracle (port of the reference) on the host cores, same batch
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -18,73 +31,111 @@ for p in (ROOT, os.path.join(ROOT, "image-compression-for-machine_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch
-import torch.distributed as dist
-
 FWD_GFLOP_PER_IMG = 68.87       # BASELINE.md section 2 (34.435 GMAC)
 STEP_GFLOP_PER_IMG = 206.6      # fwd + dgrad + wgrad
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BATCH_PER_GPU = 16
+SEED_X, SEED_NOISE = 1234, 4321
 
 
-def dominant_kernel_roofline(dev, iters=10):
-    """Time the single heaviest kernel shape live with HIP events on the launch stream: g_a.2 forward,
-    conv5x5 s2 192->192 on [16,192,128,128] (3.77 GMAC/img: SURVEY.md 8 a3)."""
+def make_workload(model_name, dev, rank=0, group=None, batch=BATCH_PER_GPU):
+    """(trainer, x, cpu state-dict): default-initialised model under torch.manual_seed(0) (identical on every rank),
+    x = rand(batch,3,256,256) from a per-rank generator (seed 1234 + rank), training noise from the trainer's own
+    per-rank generator (seed 4321 + rank).  tests/test_gpu_b16.py rebuilds exactly this and checks it against the
+    CPU oracle."""
+    import torch
+    from icm_amd.zoo import models
+    from icm_amd.trainer import Trainer
+    torch.manual_seed(0)
+    net = models[model_name]()
+    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
+    tr = Trainer(net, lr=1e-4, aux_lr=1e-4, lmbda=0.0067, clip_max_norm=1.0, device=dev, group=group, seed=SEED_NOISE)
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED_X + rank)
+    x = torch.rand(batch, 3, 256, 256, generator=g, device=dev)
+    return tr, x, sd_cpu
+
+
+def family_of(label):
+    if label.startswith("wgrad"):
+        return "wgrad_kernel + wgrad_reduce_kernel (weight gradients)"
+    if label.startswith("winattn"):
+        return "winattn kernels (window attention core)"
+    if label.startswith("pack"):
+        return "pack_weights kernels"
+    return "conv_igemm_kernel (forward + input gradients)"
+
+
+def shape_table(run_step, top=24):
+    """One extra step with every MFMA-family launch bracketed by HIP events on its launch stream (engine.PROFILE),
+    weight gradients serialised on the main stream so that each launch is timed with the chip to itself."""
+    import torch
     from icm_amd import engine as E
-    from icm_amd.engine import VT
-    x = torch.randn(BATCH_PER_GPU, 192, 128, 128, device=dev)
-    w = torch.randn(192, 192, 5, 5, device=dev) * 0.02
-    b = torch.zeros(192, device=dev)
-    tape = E.Tape(need_grad=False)
-    y = E.conv2d(tape, VT(x), w, b, stride=2, pad=2)
+    E.PROFILE = []
     torch.cuda.synchronize()
-    s = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for _ in range(iters):
-        E.conv2d(tape, VT(x), w, b, stride=2, pad=2, out=y)
-    e1.record(s)
+    t0 = time.perf_counter()
+    run_step()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flop = 2.0 * BATCH_PER_GPU * 192 * 192 * 25 * 64 * 64
-    # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    # runs, FETCH_SIZE doubled per the gfx950 correction): tools/pmc_dominant.sh + tools/pmc_dominant_summary.py ->
-    # profiles/r01_v9_pmc_dominant.json.
-    traffic = None
+    wall = (time.perf_counter() - t0) * 1e3
+    recs, E.PROFILE = E.PROFILE, None
+    agg, fam = {}, {}
+    for label, flop, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        a = agg.setdefault(label, [0.0, 0.0, 0])
+        a[0] += ms; a[1] += flop; a[2] += 1
+        f = fam.setdefault(family_of(label), [0.0, 0.0, 0])
+        f[0] += ms; f[1] += flop; f[2] += 1
+    tot = sum(v[0] for v in agg.values())
+    rows = []
+    for label, (ms, flop, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
+        tf = flop / ms / 1e9 if ms > 0 else 0.0
+        rows.append({"shape": label, "launches": cnt, "ms": round(ms, 4), "share": round(ms / tot, 4),
+                     "gflop": round(flop / 1e9, 3), "tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+    fams = {}
+    for name, (ms, flop, cnt) in fam.items():
+        tf = flop / ms / 1e9 if ms > 0 else 0.0
+        fams[name] = {"launches": cnt, "ms": round(ms, 3), "share": round(ms / tot, 4), "gflop": round(flop / 1e9, 2),
+                      "tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+    return rows, fams, tot, wall
+
+
+def pmc_traffic(kind):
+    """HBM bytes per launch of the family's heaviest launch from the committed rocprofv3 PMC passes of this round
+    (separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_family.sh)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_v9_pmc_dominant.json")) as fh:
-            traffic = json.load(fh)["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_family.json")) as fh:
+            return json.load(fh).get(kind)
     except Exception:
-        pass
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel (g_a.2 fwd: conv5x5 s2 192->192 @ [16,192,128,128])",
-            "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-            "traffic_note": "HBM bytes/launch from committed PMC passes (not re-measured in this run)",
-            "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop}
+        return None
 
 
-def cpu_baseline(sd_cpu, threads):
-    """The CPU oracle (port of the reference forward/backward) timed on the host cores: B=2 sample of the
-    same workload (fwd + loss + bwd), a few iterations, bounded to ~20 s."""
+def cpu_baseline(sd_cpu, threads, x_cpu):
+    """The CPU oracle (port of the reference forward / backward) timed on the host cores on the SAME batch
+    (B=16, 256x256): forward + R-D loss + backward, 1 warm-up + 3 timed iterations."""
+    import torch
     from oracle import wacnn_oracle as O
     torch.set_num_threads(threads)
-    B = 2
-    x = torch.rand(B, 3, 256, 256)
-    noise = {"z": torch.rand(B, 192, 4, 4) - 0.5, "y": torch.rand(B, 320, 16, 16) - 0.5}
+    B = x_cpu.shape[0]
+    g = torch.Generator().manual_seed(7)
+    noise = {"z": torch.rand(B, 192, 4, 4, generator=g) - 0.5, "y": torch.rand(B, 320, 16, 16, generator=g) - 0.5}
     s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd_cpu.items()}
 
     def it():
-        out = O.wacnn_forward(s, x, noise)
-        O.rd_loss(x, out, 0.0067)["loss"].backward()
+        for v in s.values():
+            if isinstance(v, torch.Tensor) and v.requires_grad:
+                v.grad = None
+        out = O.wacnn_forward(s, x_cpu, noise)
+        O.rd_loss(x_cpu, out, 0.0067)["loss"].backward()
     it()
     t0 = time.time()
     n = 0
-    while n < 3 or (time.time() - t0 < 12 and n < 20):
+    while n < 3:
         it()
         n += 1
     dt = (time.time() - t0) / n
     return {"value": B / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fwd+loss+bwd, B={B} 256x256, {n} iterations, {dt*1e3:.0f} ms/iter"}
+            "sample": f"oracle fwd+loss+bwd on the bench batch, B={B} 256x256, 1 warm-up + {n} iterations, "
+                      f"{dt*1e3:.0f} ms/iter"}
 
 
 def main():
@@ -93,13 +144,29 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shape-table", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="time eval-mode forward only (reported separately)")
     ap.add_argument("--model", default="cnn", choices=["cnn", "stf"], help="cnn = BASELINE.json headline (default); "
                     "stf = configs[3], reported as an extra line")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start one rank per GPU as CHILD processes (nothing here has touched the GPU
+        # yet; a GPU-initialised process must never exec) and pass their exit code on
+        port = os.environ.get("MASTER_PORT", "29541")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
     # rehearsal on a one-GPU box: ICM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend
     share = os.environ.get("ICM_BENCH_SHARE_GPU", "0") == "1"
     if share:
@@ -109,15 +176,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=world)
-    from icm_amd.zoo import models
-    from icm_amd.trainer import Trainer
-    torch.manual_seed(0)
-    net = models[args.model]()
-    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
-    tr = Trainer(net, lr=1e-4, aux_lr=1e-4, lmbda=0.0067, clip_max_norm=1.0, device=dev)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    x = torch.rand(BATCH_PER_GPU, 3, 256, 256, generator=g, device=dev)
+    tr, x, sd_cpu = make_workload(args.model, dev, rank)
 
     packed = {}   # eval forward: weights are constant, the MFMA-order copies are packed once (inference serving path)
 
@@ -130,8 +189,11 @@ def main():
             return None
         return tr.step(x)
 
-    for _ in range(args.warmup):
-        one()
+    first = None
+    for i in range(args.warmup):
+        r = one()
+        if i == 0 and r is not None:
+            first = r.tolist()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -148,6 +210,17 @@ def main():
         t = torch.tensor([dt], device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    last = scal.tolist() if scal is not None else None
+
+    # ---- per-shape / per-family roofline: one extra step outside the timed region (every rank runs it: it contains
+    # the same collectives), weight gradients serialised on the main stream
+    rows = fams = None
+    if not args.no_shape_table:
+        side = tr.side
+        tr.side = None
+        rows, fams, ktot, wall = shape_table(one)
+        tr.side = side
+
     if rank == 0:
         ips = world * BATCH_PER_GPU * args.steps / dt
         gflop = FWD_GFLOP_PER_IMG if args.fwd_only else STEP_GFLOP_PER_IMG
@@ -168,12 +241,29 @@ def main():
                               "unit": "TFLOP/s", "frac": ips / world * gflop / 1e3 / PEAK_F32_MFMA_TFLOPS,
                               "algorithmic_gflop_per_image": gflop},
         }
-        if scal is not None:
-            v = scal.tolist()
-            line["last_step"] = {"bpp": v[0], "mse": v[1], "loss": v[2], "aux": v[6]}
-        line["roofline"] = dominant_kernel_roofline(dev)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd_cpu, min(os.cpu_count() or 1, 16))
+        if first is not None:
+            line["first_step"] = {"bpp": first[0], "mse": first[1], "loss": first[2], "aux": first[6]}
+        if last is not None:
+            line["last_step"] = {"bpp": last[0], "mse": last[1], "loss": last[2], "aux": last[6]}
+        if fams:
+            cand = {k: v for k, v in fams.items() if v["share"] >= 0.15 and v["gflop"] > 0}
+            name = min(cand, key=lambda k: cand[k]["frac"]) if cand else max(fams, key=lambda k: fams[k]["share"])
+            f = fams[name]
+            kind = "wgrad" if name.startswith("wgrad") else "conv"
+            line["roofline"] = {
+                "bound": "mfma", "kernel": name, "achieved": f["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": f["frac"], "traffic": pmc_traffic(kind),
+                "share_of_step_kernel_time": f["share"], "launches": f["launches"],
+                "algorithmic_gflop": f["gflop"], "family_ms": f["ms"],
+                "avg_launch_ms": f["ms"] / max(1, f["launches"]),
+                "note": "family aggregate over one serialised step: sum of algorithmic FLOP of its launches / sum of "
+                        "their HIP-event durations on the launch stream; traffic = HBM bytes of the family's heaviest "
+                        "launch from the committed PMC passes (profiles/r02_pmc_family.json), null if absent"}
+            line["roofline_families"] = fams
+            line["roofline_shapes"] = rows
+            line["profiled_step"] = {"kernel_ms_sum": round(ktot, 3), "wall_ms": round(wall, 3)}
+        if world == 1 and not args.no_cpu_baseline and args.model == "cnn":
+            line["cpu_baseline"] = cpu_baseline(sd_cpu, min(os.cpu_count() or 1, 16), x.cpu())
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -673,10 +673,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   }
   const long long nblk = (long long)d.ncb * d.tiles_x * d.tiles_y * d.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
-  if (bg.lds_bytes > 64 * 1024) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)bg.lds_bytes);
-  }
+  if (bg.lds_bytes > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(c.fn))) return ICM_ERR_LAUNCH;
   hipLaunchKernelGGL(c.fn, dim3((unsigned)nblk, ngroups, 1), dim3(512), bg.lds_bytes, stream, d);
   ICM_CHECK_LAUNCH();
   return ICM_OK;

@@ -433,6 +433,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   }
 }
 
+// test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4>, 3 = <3,3,9,wave-split>;
+// XCD-aware workgroup order 0 / 1; -1 = automatic choice
+static int g_force_variant = -1, g_force_xcd = -1;
+
 struct WgPlan {
   int ta, tb, nacc, tpg, ws;
   int lgTW, lgTH, lgTI, lgNPX, PH, PW, PP, CS;
@@ -462,18 +466,26 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       return (size_t)2 * (ta * 32 * ((1 << lg) + 1) + tb * 32 * p.CS) * 4;
     };
     p.ws = 0;
-    if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) {
-      p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; ok = true;
+    auto variant = [&](int v) -> bool {   // kernel variant v for this tile size; false if its LDS does not fit
+      switch (v) {
+        case 3: if (lds_of(3, 3) > 150 * 1024) return false; p.ta = 3; p.tb = 3; p.nacc = 9; p.tpg = 1; p.ws = 1; return true;
+        case 2: if (lds_of(4, 4) > 150 * 1024) return false; p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; return true;
+        case 1: if (lds_of(2, 2) > 150 * 1024) return false; p.ta = 2; p.tb = 2; p.nacc = 9; p.tpg = std::min(ntaps, 9); return true;
+        default:   // <=14 taps per group x 2 a-tiles = 28 tiles = 7 per MFMA wave
+          if (lds_of(2, 1) > 150 * 1024) return false;
+          p.ta = 2; p.tb = 1; p.nacc = 7; p.tpg = ntaps <= 14 ? ntaps : (ntaps + 1) / 2;
+          return p.tpg <= 14;
+      }
+    };
+    if (g_force_variant >= 0) ok = variant(g_force_variant);
+    else if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) {
       // 96 x 96 wave-split tiles when they waste less of the padded (a, b) rectangle than 128 x 128
       const double pad128 = (double)cdiv(a.Ca, 128) * 128 * cdiv(a.Cb, 128) * 128;
       const double pad96 = (double)cdiv(a.Ca, 96) * 96 * cdiv(a.Cb, 96) * 96;
-      if (lg == 6 && pad96 * 1.05 <= pad128) { p.ta = 3; p.tb = 3; p.nacc = 9; p.ws = 1; }
+      ok = variant((lg == 6 && pad96 * 1.05 <= pad128) ? 3 : 2);
     }
-    else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) { p.ta = 2; p.tb = 2; p.nacc = 9; p.tpg = ntaps; ok = true; }
-    else if (lds_of(2, 1) <= 150 * 1024) {   // <=14 taps per group x 2 a-tiles = 28 tiles = 7 per MFMA wave
-      p.ta = 2; p.tb = 1; p.nacc = 7; p.tpg = ntaps <= 14 ? ntaps : (ntaps + 1) / 2; ok = true;
-      if (p.tpg > 14) ok = false;
-    }
+    else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) ok = variant(1);
+    else ok = variant(0);
     if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
     if (ok) p.lds = lds_of(p.ta, p.tb);
   }
@@ -563,6 +575,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   d.Ca = a->Ca; d.OH = a->OH; d.OW = a->OW; d.act_s = a->act_s;
   d.xcd_order = ((long long)a->N * a->OH * a->OW >= 16384) ? 1 : 0;
+  if (icm::g_force_xcd >= 0) d.xcd_order = icm::g_force_xcd;
   d.S = a->stride; d.pad = a->pad; d.ntaps = ntaps; d.tpg = p.tpg;
   d.lgTW = p.lgTW; d.lgTH = p.lgTH; d.lgTI = p.lgTI; d.lgNPX = p.lgNPX;
   d.tiles_x = p.tiles_x; d.tiles_y = p.tiles_y; d.tiles_n = p.tiles_n; d.ntiles = p.ntiles; d.nsplit = p.nsplit;
@@ -585,8 +598,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   else if (p.ta == 4) fn = wgrad_kernel<4, 4, 4>;
   else if (p.tb == 2) fn = wgrad_kernel<2, 2, 9>;
   else fn = wgrad_kernel<2, 1, 7>;
-  if (p.lds > 64 * 1024)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+  if (p.lds > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(fn))) return ICM_ERR_LAUNCH;
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, n), dim3(512), p.lds, stream, d);
   ICM_CHECK_LAUNCH();
   r.Ca = a->Ca; r.Cb = a->Cb; r.ntaps = ntaps; r.nsplit = nslab; r.nsplit_bias = p.nsplit;
@@ -604,6 +616,11 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks, n), dim3(256), 0, stream, r);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
+}
+
+void icm_debug_force_wgrad_cfg(int variant, int xcd_order) {
+  icm::g_force_variant = (variant >= 0 && variant <= 3) ? variant : -1;
+  icm::g_force_xcd = (xcd_order == 0 || xcd_order == 1) ? xcd_order : -1;
 }
 
 int icm_conv_wgrad(const icm_wgrad_args* a, void* stream_) {

@@ -270,10 +270,12 @@ __global__ __launch_bounds__(256) void eb_aux_kernel(const EbPtrs P, float* loss
     for (int i = 0; i < 59; ++i) scratch[i] = 0.0f;
     dq[e] = eb_chain_bwd(ch, v, tr, sg, scratch);
   }
+  // ONE workgroup (C * 3 = 576 chain evaluations): fixed-order sum, no float atomics (every data-parallel rank
+  // must see the same value)
   part = wave_sum(part);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) *loss = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------ GaussianConditional
@@ -392,8 +394,7 @@ int icm_eb_likelihood_bwd(const float* z, const float* noise, const icm_eb_param
 
 int icm_eb_aux_loss(const icm_eb_params* p, float* loss, float* dquantiles, int C, float target, void* stream) {
   if (!eb_ok(p) || !loss || !dquantiles || C <= 0) return ICM_ERR_ARG;
-  hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
-  hipLaunchKernelGGL(eb_aux_kernel, dim3(std::min(64, (C * 3 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(eb_aux_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                      to_ptrs(p), loss, dquantiles, C, target);
   ICM_CHECK_LAUNCH();
   return ICM_OK;

@@ -15,6 +15,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace icm {
 
+// Kernels that may use more than the default 64 KB of dynamic LDS get the attribute raised ONCE (first launch of
+// that kernel in the process), not on every launch.  Thread-safe; returns false if the runtime refuses.
+bool ensure_max_lds(const void* fn);
+
 __device__ __forceinline__ float gelu_f(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -3,7 +3,23 @@
 #include <algorithm>
 #include "icm_common.h"
 
+#include <mutex>
+#include <unordered_set>
+
 namespace icm {
+
+bool ensure_max_lds(const void* fn) {
+  static std::mutex mu;
+  static std::unordered_set<const void*> done;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count(fn)) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  done.insert(fn);
+  return true;
+}
 
 static inline int grid_for(long long n, int per_thread = 4) {
   long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
@@ -13,11 +29,25 @@ static inline int grid_for(long long n, int per_thread = 4) {
 #define GRID_STRIDE(i, n) \
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
+// ---------------------------------------------------------------- deterministic block reduction
+// No float atomics anywhere in the library: every rank of a data-parallel job must derive bit-identical sums from
+// bit-identical inputs (clip coefficient, bias / LayerNorm / table gradients), whatever the workgroup arrival order.
+// Fixed tree: lanes by wave_sum (xor butterfly), waves in index order.
+__device__ __forceinline__ float block_sum256(float v, float* red /* >= 4 floats of LDS */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---------------------------------------------------------------- channel sum: out[c] = sum_{n,p} x[n,c,p]
-// grid (C, S): each workgroup reduces one pixel chunk of one channel and adds its partial with one float atomic
-// (out is zeroed by a memset node first unless accumulating); float4 loads when the plane allows
+// grid (C, S): workgroup (c, s) reduces pixel chunk s of channel c (strided assignment: fixed for a given shape).
+// S == 1: the workgroup writes out[c] itself; S > 1: partials go to ws[s][c] and channel_sum_finish adds them in
+// split order.  float4 loads when the plane allows.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, long long bs, int N, int C,
-                                                          int HW, float* __restrict__ out) {
+                                                          int HW, float* __restrict__ out, float* __restrict__ ws,
+                                                          int accum) {
   __shared__ float red[4];
   const int c = blockIdx.x, S = gridDim.y, sp = blockIdx.y;
   float s = 0.0f;
@@ -36,10 +66,22 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
       s += x[n * bs + (long long)c * HW + p];
     }
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out + c, red[0] + red[1] + red[2] + red[3]);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) {
+    if (S == 1) out[c] = accum ? out[c] + s : s;
+    else ws[(long long)sp * C + c] = s;
+  }
+}
+// out[k*C + c] (+)= sum_s ws[(k*S + s)*C + c]   (K independent quantities, S partials each, added in split order)
+__global__ void split_sum_finish_kernel(const float* __restrict__ ws, float* __restrict__ out0,
+                                        float* __restrict__ out1, int C, int S, int K, int accum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * K) return;
+  const int k = i / C, c = i - k * C;
+  float s = 0.0f;
+  for (int j = 0; j < S; ++j) s += ws[((long long)k * S + j) * C + c];
+  float* o = (k == 0 ? out0 : out1) + c;
+  *o = accum ? *o + s : s;
 }
 
 // ---------------------------------------------------------------- NonNegativeParametrizer
@@ -336,14 +378,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cached_kernel(const float* 
     }
   }
 }
-// dgamma[c] += sum_{n,p} dy * xhat ; dbeta[c] += sum dy.  grid (C, S): workgroup (c, s) reduces pixel chunk s of
-// channel c and adds its partial with one float atomic per output (outputs zeroed first unless accumulating)
+// dgamma[c] (+)= sum_{n,p} dy * xhat ; dbeta[c] (+)= sum dy.  grid (C, S): workgroup (c, s) reduces pixel chunk s of
+// channel c; S == 1 writes the outputs, S > 1 writes partials ws[{gamma,beta}][s][c] for split_sum_finish_kernel
+// (deterministic: no float atomics)
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, long long xbs,
                                                                    const float* __restrict__ dy, long long dbs,
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, float* dgamma,
-                                                                   float* dbeta, int N, int C, int HW) {
-  __shared__ float red[2][4];
+                                                                   float* dbeta, float* __restrict__ ws, int N, int C,
+                                                                   int HW, int accum) {
+  __shared__ float red[4];
   const int c = blockIdx.x, S = gridDim.y, sp = blockIdx.y;
   float sg = 0.0f, sb = 0.0f;
   const long long total = (long long)N * HW;
@@ -354,13 +398,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* 
     sg += g * xh;
     sb += g;
   }
-  sg = wave_sum(sg);
-  sb = wave_sum(sb);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sg; red[1][threadIdx.x >> 6] = sb; }
-  __syncthreads();
+  sg = block_sum256(sg, red);
+  sb = block_sum256(sb, red);
   if (threadIdx.x == 0) {
-    atomicAdd(dgamma + c, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
-    atomicAdd(dbeta + c, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    if (S == 1) {
+      dgamma[c] = accum ? dgamma[c] + sg : sg;
+      dbeta[c] = accum ? dbeta[c] + sb : sb;
+    } else {
+      ws[(long long)sp * C + c] = sg;
+      ws[((long long)S + sp) * C + c] = sb;
+    }
   }
 }
 // PatchMerging gather (stf.py:224-228): dst[n][k*C + c][y][x] = src[n][c][2y + (k&1)][2x + (k>>1)]; inverse = its gradient
@@ -450,15 +497,10 @@ __global__ void fill_kernel(float* p, long long n, float v) {
 }
 
 // ---------------------------------------------------------------- R-D loss
-__device__ __forceinline__ void block_atomic_add(float v, float* dst, float* red) {
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dst, red[0] + red[1] + red[2] + red[3]);
-  __syncthreads();
-}
+// stage 1: per-workgroup partial sums of (squared error, log lik_y, log lik_z) into ws[3][nblk];
+// stage 2 (one workgroup): adds the partials in block order and forms bpp / mse / loss.  Deterministic.
 __global__ __launch_bounds__(256) void rd_reduce_kernel(const float* x, const float* xh, long long nx, const float* ly,
-                                                        long long ny, const float* lz, long long nz, float* out) {
+                                                        long long ny, const float* lz, long long nz, float* ws) {
   __shared__ float red[4];
   float se = 0.0f, sy = 0.0f, sz = 0.0f;
   GRID_STRIDE(i, nx) {
@@ -467,18 +509,36 @@ __global__ __launch_bounds__(256) void rd_reduce_kernel(const float* x, const fl
   }
   GRID_STRIDE(i, ny) sy += logf(ly[i]);
   GRID_STRIDE(i, nz) sz += logf(lz[i]);
-  block_atomic_add(se, out + 1, red);
-  block_atomic_add(sy, out + 3, red);
-  block_atomic_add(sz, out + 4, red);
+  se = block_sum256(se, red);
+  sy = block_sum256(sy, red);
+  sz = block_sum256(sz, red);
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = se;
+    ws[gridDim.x + blockIdx.x] = sy;
+    ws[2 * gridDim.x + blockIdx.x] = sz;
+  }
 }
-__global__ void rd_finish_kernel(float* out, long long nx, long long npix, float lmbda) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float mse = out[1] / (float)nx;
+// sum of nblk partials in fixed order by one 256-thread workgroup (thread t takes t, t+256, ...)
+__device__ __forceinline__ float ordered_sum(const float* p, int nblk, float* red) {
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += p[i];
+  return block_sum256(s, red);
+}
+__global__ __launch_bounds__(256) void rd_finish_kernel(const float* ws, int nblk, float* out, long long nx,
+                                                        long long npix, float lmbda) {
+  __shared__ float red[4];
+  const float se = ordered_sum(ws, nblk, red);
+  const float sy = ordered_sum(ws + nblk, nblk, red);
+  const float sz = ordered_sum(ws + 2 * nblk, nblk, red);
+  if (threadIdx.x == 0) {
+    const float mse = se / (float)nx;
     const float denom = -0.69314718055994530942f * (float)npix;
-    const float bpp = out[3] / denom + out[4] / denom;
+    const float bpp = sy / denom + sz / denom;
     out[0] = bpp;
     out[1] = mse;
     out[2] = lmbda * 65025.0f * mse + bpp;
+    out[3] = sy;
+    out[4] = sz;
   }
 }
 __global__ void rd_bwd_kernel(const float* x, const float* xh, long long nx, const float* ly, long long ny,
@@ -492,7 +552,7 @@ __global__ void rd_bwd_kernel(const float* x, const float* xh, long long nx, con
 }
 
 // ---------------------------------------------------------------- optimiser
-__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* out) {
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n, float* ws) {
   __shared__ float red[4];
   float s = 0.0f;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
@@ -504,7 +564,13 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long long n
   for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)
     s += g[i] * g[i];
-  block_atomic_add(s, out, red);
+  s = block_sum256(s, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sqnorm_finish_kernel(const float* ws, int nblk, float* out) {
+  __shared__ float red[4];
+  const float s = ordered_sum(ws, nblk, red);
+  if (threadIdx.x == 0) out[0] = s;
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float step_size, float b1, float b2, float omb1,
@@ -532,13 +598,21 @@ using namespace icm;
 
 extern "C" {
 
-int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, void* stream) {
+int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, float* ws,
+                    int64_t ws_floats, void* stream) {
   if (!x || !out || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
-  if (!accum) hipMemsetAsync(out, 0, (size_t)C * sizeof(float), ST);
   const long long per_c = (long long)N * HW;
-  const int S = (int)std::max<long long>(1, std::min<long long>(32, per_c / 16384));
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(256), 0, ST, x, (long long)x_bs, N, C, HW, out);
+  long long S = std::max<long long>(1, std::min<long long>(32, per_c / 16384));
+  if (!ws) S = 1;
+  else S = std::max<long long>(1, std::min<long long>(S, ws_floats / C));
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, (unsigned)S), dim3(256), 0, ST, x, (long long)x_bs, N, C, HW, out, ws,
+                     accum);
   ICM_CHECK_LAUNCH();
+  if (S > 1) {
+    hipLaunchKernelGGL(split_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, ws, out, out, C, (int)S, 1,
+                       accum);
+    ICM_CHECK_LAUNCH();
+  }
   return ICM_OK;
 }
 int icm_nonneg_fwd(const float* p, float* out, int64_t n, float bound, float pedestal, void* stream) {
@@ -637,7 +711,7 @@ int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const fl
 int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t dx_bs, float* dgamma, float* dbeta,
                       int N, int C, int HW, int accum_dx, int accum_params, const float* dx_extra, int64_t dx_extra_bs,
-                      void* stream) {
+                      float* ws, int64_t ws_floats, void* stream) {
   if (!x || !dy || !gamma || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   if (dx) {
     const long long tiles = ((long long)N * HW + 63) / 64;
@@ -656,16 +730,19 @@ int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
     ICM_CHECK_LAUNCH();
   }
   if (dgamma && dbeta) {
-    if (!accum_params) {
-      if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, ST) != hipSuccess) return ICM_ERR_LAUNCH;
-      if (hipMemsetAsync(dbeta, 0, sizeof(float) * C, ST) != hipSuccess) return ICM_ERR_LAUNCH;
-    }
     // enough pixel chunks to fill the chip whatever C is (C = 48 at the 128x128 level)
     const long long chunks = ((long long)N * HW + 4095) / 4096;
-    const int S = (int)std::max<long long>(1, std::min<long long>(chunks, (2048 + C - 1) / C));
-    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(C, S), dim3(256), 0, ST, x, (long long)x_bs, dy,
-                       (long long)dy_bs, mean, rstd, dgamma, dbeta, N, C, HW);
+    long long S = std::max<long long>(1, std::min<long long>(chunks, (2048 + C - 1) / C));
+    if (!ws) S = 1;
+    else S = std::max<long long>(1, std::min<long long>(S, ws_floats / (2LL * C)));
+    hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(C, (unsigned)S), dim3(256), 0, ST, x, (long long)x_bs, dy,
+                       (long long)dy_bs, mean, rstd, dgamma, dbeta, ws, N, C, HW, accum_params);
     ICM_CHECK_LAUNCH();
+    if (S > 1) {
+      hipLaunchKernelGGL(split_sum_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ST, ws, dgamma, dbeta, C,
+                         (int)S, 2, accum_params);
+      ICM_CHECK_LAUNCH();
+    }
   }
   return ICM_OK;
 }
@@ -710,13 +787,15 @@ int icm_fill(float* p, int64_t n, float v, void* stream) {
   return ICM_OK;
 }
 int icm_rd_loss_fwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
-                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, void* stream) {
-  if (!x || !x_hat || !lik_y || !lik_z || !out || n_img_elems <= 0 || num_pixels <= 0) return ICM_ERR_ARG;
-  hipLaunchKernelGGL(rd_reduce_kernel, dim3(grid_for(n_img_elems, 8)), dim3(256), 0, ST, x, x_hat,
-                     (long long)n_img_elems, lik_y, (long long)n_y, lik_z, (long long)n_z, out);
+                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, float* ws,
+                    void* stream) {
+  if (!x || !x_hat || !lik_y || !lik_z || !out || !ws || n_img_elems <= 0 || num_pixels <= 0) return ICM_ERR_ARG;
+  const int nblk = grid_for(n_img_elems, 8);   // <= 2048: 3 * nblk <= ICM_REDUCE_WS_FLOATS
+  hipLaunchKernelGGL(rd_reduce_kernel, dim3(nblk), dim3(256), 0, ST, x, x_hat, (long long)n_img_elems, lik_y,
+                     (long long)n_y, lik_z, (long long)n_z, ws);
   ICM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rd_finish_kernel, dim3(1), dim3(64), 0, ST, out, (long long)n_img_elems, (long long)num_pixels,
-                     lmbda);
+  hipLaunchKernelGGL(rd_finish_kernel, dim3(1), dim3(256), 0, ST, ws, nblk, out, (long long)n_img_elems,
+                     (long long)num_pixels, lmbda);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
@@ -730,9 +809,12 @@ int icm_rd_loss_bwd(const float* x, const float* x_hat, int64_t n_img_elems, con
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
-int icm_grad_sqnorm(const float* g, int64_t n, float* out, void* stream) {
-  if (!g || !out || n <= 0) return ICM_ERR_ARG;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 16)), dim3(256), 0, ST, g, (long long)n, out);
+int icm_grad_sqnorm(const float* g, int64_t n, float* out, float* ws, void* stream) {
+  if (!g || !out || !ws || n <= 0) return ICM_ERR_ARG;
+  const int nblk = grid_for(n, 16);   // <= 2048 <= ICM_REDUCE_WS_FLOATS
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(nblk), dim3(256), 0, ST, g, (long long)n, ws);
+  ICM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sqnorm_finish_kernel, dim3(1), dim3(256), 0, ST, ws, nblk, out);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -10,8 +10,8 @@
 // head live in LDS (broadcast reads), the score row lives in a per-wave LDS matrix with odd row stride
 // (conflict-free row and column sweeps), so the backward pass gets P^T / dS^T for dV, dK without any
 // cross-lane shuffles.  Relative-position-bias gradients are reduced per wave in LDS (all lanes of one
-// instruction hit distinct table entries) and flushed with one atomicAdd per table entry per workgroup.
-// TODO(next round): QK^T / PV on v_mfma_f32_16x16x4_f32; they are 0.6 % of the model FLOPs.
+// instruction hit distinct table entries); every (window, head) writes its partial table to a workspace slab
+// and two small kernels add the slabs in window order: bitwise reproducible, no float atomics.
 #include <algorithm>
 #include "icm_common.h"
 
@@ -23,7 +23,7 @@ struct WaDesc {
   float* out;          // fwd
   const float* dout;   // bwd
   float* dqkv;         // bwd
-  float* dtable;       // bwd
+  float* dtable_ws;    // bwd: per-(window, head) partial tables [nwin][heads][(2ws-1)^2]
   int N, C, H, W, heads, ws, shift, hd, T, nwx, nwy, G;
   float scale;
 };
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
     const int xcd = hb & 7, q = hb >> 3;
     bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
   }
+  const int win = bid;
   const int wx = bid % d.nwx; bid /= d.nwx;
   const int wy = bid % d.nwy;
   const int n = bid / d.nwy;
@@ -306,14 +307,40 @@ __global__ __launch_bounds__(128) void winattn_bwd_kernel(const WaDesc d) {
 #pragma unroll
       for (int dd = 0; dd < HD; ++dd) dk[dd * HW + me.pix] = acc[dd];
     }
-    if (active)
-      for (int i = lane; i < ntab; i += T) {
-        const float v = Bsh[i];
-        if (v != 0.0f) atomicAdd(d.dtable + i * d.heads + head, v);
-      }
+    if (active) {
+      float* slab = d.dtable_ws + ((long long)win * d.heads + head) * ntab;
+      for (int i = lane; i < ntab; i += T) slab[i] = Bsh[i];
+    }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// Table-gradient reduction, stage 1: part[s][e] = sum over the windows of chunk s of slab[w][e], e = head*ntab + i.
+// Workgroup = 64 entries x 4 window lanes; window lanes are combined in lane order through LDS.
+__global__ __launch_bounds__(256) void dtable_reduce1_kernel(const float* __restrict__ slabs, float* __restrict__ part,
+                                                             int E, int nwin, int chunk) {
+  __shared__ float red[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), wl = threadIdx.x >> 6, s = blockIdx.y;
+  const int w0 = s * chunk, w1 = min(nwin, w0 + chunk);
+  float acc = 0.0f;
+  if (e < E)
+    for (int w = w0 + wl; w < w1; w += 4) acc += slabs[(long long)w * E + e];
+  red[wl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (wl == 0 && e < E)
+    part[(long long)s * E + e] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// stage 2: dtable[i*heads + head] (+)= sum_s part[s][head*ntab + i]
+__global__ void dtable_reduce2_kernel(const float* __restrict__ part, float* __restrict__ dtable, int E, int S,
+                                      int ntab, int heads, int accum) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float acc = 0.0f;
+  for (int s = 0; s < S; ++s) acc += part[(long long)s * E + e];
+  const int head = e / ntab, i = e - head * ntab;
+  float* o = dtable + i * heads + head;
+  *o = accum ? *o + acc : acc;
 }
 
 typedef void (*WaFn)(const WaDesc);
@@ -359,19 +386,39 @@ int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int
   const int waves = std::min(4, (heads + d.G - 1) / d.G);
   const size_t lds = (size_t)waves * d.G * (2 * d.T * d.hd + d.T * (d.T + 1)) * 4;
   if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(f))) return ICM_ERR_LAUNCH;
   hipLaunchKernelGGL(f, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
 
-int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable, int N, int C,
-                    int H, int W, int heads, int ws, int shift, void* stream) {
-  if (!qkv || !table || !dout || !dqkv || !dtable) return ICM_ERR_ARG;
+static void dtable_plan(int N, int H, int W, int heads, int ws, int& nwin, int& E, int& S, int& chunk) {
+  const int tw = 2 * ws - 1;
+  nwin = N * (H / ws) * (W / ws);
+  E = heads * tw * tw;
+  S = std::max(1, std::min(64, nwin / 16));
+  chunk = (nwin + S - 1) / S;
+  S = (nwin + chunk - 1) / chunk;
+}
+
+int64_t icm_winattn_bwd_workspace_floats(int N, int C, int H, int W, int heads, int ws) {
+  if (N <= 0 || heads <= 0 || ws <= 0 || H % ws || W % ws) return -1;
+  int nwin, E, S, chunk;
+  dtable_plan(N, H, W, heads, ws, nwin, E, S, chunk);
+  return (int64_t)nwin * E + (int64_t)S * E;
+}
+
+int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
+                    int accum_table, float* wsp, int64_t ws_floats, int N, int C, int H, int W, int heads, int ws,
+                    int shift, void* stream) {
+  if (!qkv || !table || !dout || !dqkv || !dtable || !wsp) return ICM_ERR_ARG;
   WaDesc d{};
   int rc = fill_desc(d, N, C, H, W, heads, ws, shift);
   if (rc) return rc;
-  d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable = dtable;
+  int nwin, E, S, chunk;
+  dtable_plan(N, H, W, heads, ws, nwin, E, S, chunk);
+  if (ws_floats < (int64_t)nwin * E + (int64_t)S * E) return ICM_ERR_ARG;
+  d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable_ws = wsp;
   WaFn f, b;
   if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
   const int waves = std::min(2, (heads + d.G - 1) / d.G);
@@ -379,8 +426,15 @@ int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, flo
   if (tw * tw > d.T * d.hd) return ICM_ERR_UNSUPPORTED;   // the table gradient is accumulated in the dO region
   const size_t lds = (size_t)waves * d.G * ((3 * d.T * d.hd + d.T * (d.T + 1) + 3) & ~3) * 4;
   if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(b))) return ICM_ERR_LAUNCH;
   hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
+  ICM_CHECK_LAUNCH();
+  float* part = wsp + (long long)nwin * E;
+  hipLaunchKernelGGL(dtable_reduce1_kernel, dim3((E + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, wsp, part, E,
+                     nwin, chunk);
+  ICM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dtable_reduce2_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, dtable, E, S,
+                     tw * tw, heads, accum_table);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

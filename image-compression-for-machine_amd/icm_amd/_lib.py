@@ -71,7 +71,9 @@ SYMBOLS = [
     "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
+    "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_wgrad_cfg",
 ]
+REDUCE_WS_FLOATS = 8192   # ICM_REDUCE_WS_FLOATS
 
 
 def lib():
@@ -97,7 +99,7 @@ def lib():
         L.icm_wgrad_workspace_floats_grouped.argtypes = [C.POINTER(WgradArgs), i32]
         L.icm_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
         L.icm_conv_wgrad_grouped.argtypes = [C.POINTER(WgradArgs), i32, vp]
-        L.icm_channel_sum.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp]
+        L.icm_channel_sum.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i64, vp]
         L.icm_nonneg_fwd.argtypes = [vp, vp, i64, f32, f32, vp]
         L.icm_nonneg_bwd.argtypes = [vp, vp, vp, i64, f32, i32, vp]
         L.icm_gdn_bwd_pre.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]
@@ -109,14 +111,21 @@ def lib():
         L.icm_lrp_bwd.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
         L.icm_pixel_unshuffle2.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.icm_layernorm_fwd.argtypes = [vp, i64, vp, vp, vp, i64, vp, vp, i32, i32, i32, f32, vp]
-        L.icm_layernorm_bwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp]
+        L.icm_layernorm_bwd.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, i64,
+                                        vp, i64, vp]
         L.icm_space_to_depth2.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.icm_residual_scale.argtypes = [vp, vp, vp, vp, i32, i64, vp]
         L.icm_im2col.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_col2im.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_copy_strided.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, vp]
         L.icm_winattn_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
-        L.icm_winattn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.icm_winattn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.icm_winattn_bwd_workspace_floats.argtypes = [i32, i32, i32, i32, i32, i32]
+        L.icm_winattn_bwd_workspace_floats.restype = i64
+        L.icm_debug_force_conv_cfg.argtypes = [i32]
+        L.icm_debug_force_conv_cfg.restype = None
+        L.icm_debug_force_wgrad_cfg.argtypes = [i32, i32]
+        L.icm_debug_force_wgrad_cfg.restype = None
         L.icm_eb_likelihood_fwd.argtypes = [vp, vp, C.POINTER(EbParams), vp, vp, i32, i32, i32, f32, vp]
         L.icm_eb_likelihood_bwd.argtypes = [vp, vp, C.POINTER(EbParams), vp, vp, C.POINTER(EbGrads), i32, i32, i32,
                                             f32, i32, vp]
@@ -125,9 +134,9 @@ def lib():
                                                 i32, i32, f32, f32, vp]
         L.icm_gc_likelihood_ste_bwd.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp,
                                                 i64, vp, i64, i32, i32, i32, f32, f32, i32, vp]
-        L.icm_rd_loss_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, vp, vp]
+        L.icm_rd_loss_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, vp, vp, vp]
         L.icm_rd_loss_bwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, f32, vp, vp, vp, vp]
-        L.icm_grad_sqnorm.argtypes = [vp, i64, vp, vp]
+        L.icm_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
         L.icm_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp, f32, f32, vp]
         L.icm_fill.argtypes = [vp, i64, f32, vp]
         _lib = L

@@ -28,6 +28,42 @@ _SKIP_WGRAD = _os.environ.get("ICM_DEBUG_SKIP_WGRAD", "0") == "1"
 PAIR_GATE_BRANCHES = _os.environ.get("ICM_PAIR_GATE_BRANCHES", "1") == "1"
 
 
+# In-place HIP updates (icm_adam_step) do not bump torch's tensor version counters: the trainer bumps this generation
+# after every optimiser step and every packed-weight cache key carries it, so a caller-owned ``packed_cache`` that
+# outlives a training step misses (re-packs) instead of silently serving stale weights.
+_weight_gen = [0]
+
+
+def bump_weight_generation():
+    _weight_gen[0] += 1
+
+
+# ---- per-launch profiling (bench.py's per-shape roofline table): when PROFILE is a list, every MFMA-family launch is
+# bracketed by HIP events on its launch stream and recorded as (label, algorithmic FLOP, start, end)
+PROFILE: Optional[list] = None
+
+
+def _prof_begin(stream=None):
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record(stream if stream is not None else torch.cuda.current_stream())
+    return e
+
+
+def _prof_end(e0, label: str, flop: float, stream=None):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record(stream if stream is not None else torch.cuda.current_stream())
+    PROFILE.append((label, flop, e0, e1))
+
+
+def _conv_label(tag, transposed, KH, stride, Cin, Cout, H, W, N, n=1):
+    return (f"{tag} {'scatter' if transposed else 'gather'} {KH}x{KH}s{stride} {Cin}->{Cout} @{H}x{W} n{N}"
+            + (f" x{n}" if n > 1 else ""))
+
+
 def new(shape_or_like, device=None):
     """fresh contiguous f32 device tensor (torch caching allocator = device memory plumbing)"""
     if isinstance(shape_or_like, torch.Tensor):
@@ -55,7 +91,8 @@ class Tape:
     def __init__(self, need_grad: bool = True, packed_cache: Optional[dict] = None):
         """packed_cache: a dict kept by the caller across forward calls with CONSTANT weights (inference): the packed
         MFMA-order weight copies are then produced once instead of once per call.  The cache key holds the tensor's
-        autograd version, which in-place HIP updates (icm_adam_step) do not bump -- never share a cache with training."""
+        autograd version and the engine's weight generation (bumped by Trainer.step), so entries packed before an
+        optimiser step are never served afterwards."""
         self.need_grad = need_grad
         self.bw: List[Callable[[], None]] = []
         self.grads: Dict[tuple, torch.Tensor] = {}
@@ -63,6 +100,7 @@ class Tape:
         self.stopped = set()
         self._packed: Dict[tuple, torch.Tensor] = packed_cache if packed_cache is not None else {}
         self._ws: Optional[torch.Tensor] = None
+        self._red: Optional[torch.Tensor] = None
         self.wjobs: list = []
         self.pack_log = None      # when a list: records (w, args) of every cache miss (the trainer's packing plan)
         self.pack_seq = None      # recorded miss sequence of an identical earlier step (windowed batch packing)
@@ -160,6 +198,12 @@ class Tape:
             self._flushed = []
 
     # ---- helpers
+    def red_ws(self, nfloats: int, device) -> torch.Tensor:
+        """scratch for the fixed-order (atomic-free) reductions of the main stream (bias / LayerNorm / table grads)"""
+        if self._red is None or self._red.numel() < nfloats or self._red.device != device:
+            self._red = torch.empty(max(nfloats, 1 << 16), dtype=torch.float32, device=device)
+        return self._red
+
     def workspace(self, nfloats: int, device) -> torch.Tensor:
         if self._ws is None or self._ws.numel() < nfloats:
             self._ws = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
@@ -171,7 +215,7 @@ class Tape:
         per-layer pack launches of a training step become ~40, while every packed weight is still produced just
         before its consumer (packing everything up front pushes it out of the Infinity Cache: DESIGN.md 5)."""
         args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg)
-        k = (w.data_ptr(), w._version) + args
+        k = (w.data_ptr(), w._version, _weight_gen[0]) + args
         wp = self._packed.get(k)
         if wp is not None:
             return wp
@@ -184,7 +228,7 @@ class Tape:
             if i is not None:
                 jobs_w = []
                 for (w2, a2) in seq[i:i + self.pack_window]:
-                    k2 = (w2.data_ptr(), w2._version) + a2[:9]
+                    k2 = (w2.data_ptr(), w2._version, _weight_gen[0]) + a2[:9]
                     if k2 not in self._packed:
                         wp2 = torch.empty(lib.icm_packed_weight_floats(a2[0], a2[1], a2[2], a2[3]), dtype=torch.float32,
                                           device=w2.device)
@@ -194,11 +238,15 @@ class Tape:
                 for j, (w2, a2, wp2) in zip(jobs, jobs_w):
                     j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w2), ptr(wp2), a2[0], a2[1], a2[2], a2[3]
                     j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal = a2[4:11]
+                e0 = _prof_begin()
                 check(lib.icm_pack_weights_batch(jobs, len(jobs_w), self.st), "pack_weights_batch")
+                _prof_end(e0, "pack weights (window)", 0.0)
                 return self._packed[k]
         wp = torch.empty(lib.icm_packed_weight_floats(M, K, KH, KW), dtype=torch.float32, device=w.device)
+        e0 = _prof_begin()
         check(lib.icm_pack_weights(ptr(w), ptr(wp), M, K, KH, KW, src_out_major, transposed, stride, pad,
                                    nonneg, bound, ped, self.st), "pack_weights")
+        _prof_end(e0, "pack weights (single)", 0.0)
         self._packed[k] = wp
         return wp
 
@@ -212,9 +260,10 @@ class Tape:
 
 # ------------------------------------------------------------------------------------------------ raw launches
 def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW, pro_act=ACT_NONE,
-                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0):
+                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0, tag="fwd"):
     a = L.ConvArgs()
     N, _, H, W = x.shape
+    e0 = _prof_begin()
     a.x, a.x_bs, a.N, a.Cin, a.H, a.W = ptr(x), bs(x), N, Cin, H, W
     a.wp, a.bias = ptr(wp), ptr(bias)
     a.y, a.y_bs, a.Cout, a.OH, a.OW = ptr(y), bs(y), Cout, OH, OW
@@ -226,6 +275,9 @@ def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transpo
     a.y2, a.y2_bs = ptr(y2), bs(y2)
     a.accum, a.pixel_shuffle = accum, ps
     check(L.lib().icm_conv_run(C.byref(a), tape.st), "conv_run")
+    if e0 is not None:
+        px = H * W if transposed else OH * OW
+        _prof_end(e0, _conv_label(tag, transposed, KH, stride, Cin, Cout, H, W, N), 2.0 * N * Cin * Cout * KH * KW * px)
 
 
 def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
@@ -244,7 +296,9 @@ def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NON
         raise ValueError("icm wgrad: invalid geometry")
     ws = tape.workspace(n, gs.device)
     a.ws, a.ws_floats = ptr(ws), n
+    e0 = _prof_begin()
     check(L.lib().icm_conv_wgrad(C.byref(a), tape.st), "conv_wgrad")
+    _prof_end(e0, f"wgrad {KH}x{KH}s{stride} {Cb}->{Ca} @{H}x{W} n{N}", 2.0 * N * Ca * Cb * KH * KW * OH * OW)
 
 
 def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
@@ -305,7 +359,10 @@ def flush_wgrads(tape):
                 ws = tape.workspace(n * len(chunk), chunk[0][1].device)
             for j, a in enumerate(arr):
                 a.ws, a.ws_floats = ptr(ws) + 4 * n * j, n
+            e0 = _prof_begin(side)
             check(lib.icm_conv_wgrad_grouped(arr, len(chunk), st), "conv_wgrad_grouped")
+            _prof_end(e0, f"wgrad {KH}x{KH}s{stride} {Cb}->{Ca} @{H}x{W} n{N}" + (f" x{len(chunk)}" if len(chunk) > 1 else ""),
+                      2.0 * len(chunk) * N * Ca * Cb * KH * KW * OH * OW, side)
 
 
 def accumulate(tape, dst_t, src, mul_dgelu_of=None):
@@ -320,6 +377,14 @@ def accumulate(tape, dst_t, src, mul_dgelu_of=None):
         N, Cc = src.shape[0], src.shape[1]
         HW = src.shape[2] * src.shape[3]
         check(L.lib().icm_copy_strided(ptr(src), bs(src), ptr(g), bs(g), N, Cc, HW, acc, tape.st), "copy_strided")
+
+
+def channel_sum(tape, x, out, accum):
+    """out[c] (+)= sum_{n,p} x[n,c,p] with fixed-order split partials (bias gradients, GDN d_beta)"""
+    N, Cc = x.shape[0], x.shape[1]
+    HW = x.shape[2] * x.shape[3]
+    ws = tape.red_ws(32 * Cc, x.device)
+    check(L.lib().icm_channel_sum(ptr(x), bs(x), N, Cc, HW, ptr(out), accum, ptr(ws), ws.numel(), tape.st), "channel_sum")
 
 
 def copy_into(tape, src, dst, accum=0):
@@ -392,7 +457,7 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
         fuse_b = want_b and not transposed and tape.wants(w)   # bias grad rides on the wgrad loaders
         if want_b and not fuse_b:
             gb_, acc = tape.grad_for_write(b)
-            check(L.lib().icm_channel_sum(ptr(dy), bs(dy), N, Cout, OH * OW, ptr(gb_), acc, tape.st), "channel_sum")
+            channel_sum(tape, dy, gb_, acc)
         if tape.wants(w):
             gw, acc = tape.grad_for_write(w)
             if not transposed:
@@ -414,11 +479,11 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             if not transposed:   # conv dgrad = scatter with W ([K=Cout][M=Cin])
                 wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
-                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc)
+                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc, tag="dgrad")
             else:                # convT dgrad = gather with Wt ([M=Cin][K=Cout])
                 wpb = tape.pack(w4, Cin, Cout, KH, KW, 1, 0, stride, pad)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
-                            transposed=0, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc)
+                            transposed=0, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc, tag="dgrad")
 
     tape.bw.append(bwd)
     return y
@@ -472,7 +537,7 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
             dy = dy if dy.is_contiguous() else dy.contiguous()
             if b is not None and tape.wants(b):
                 gb_, acc = tape.grad_for_write(b)
-                check(L.lib().icm_channel_sum(ptr(dy), bs(dy), N, Cout, OH * OW, ptr(gb_), acc, tape.st), "channel_sum")
+                channel_sum(tape, dy, gb_, acc)
             dt, acc = tape.grad_for_write(tmp)
             assert acc == 0
             check(L.lib().icm_im2col(ptr(dy), ptr(dt), N, Cout, OH, OW, K, stride, pad, tape.st), "im2col")
@@ -481,9 +546,10 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,
-                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0, ps=0):
+                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0, ps=0, tag="fwd"):
     n = len(xs)
     arr = (L.ConvArgs * n)()
+    e0 = _prof_begin()
     for i, a in enumerate(arr):
         x, y = xs[i], ys[i]
         N, _, H, W = x.shape
@@ -503,6 +569,11 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
                   or bs(y2) != bs(y2s[0] if y2s else None) or bs(res) != bs(ress[0] if ress else None)):
             raise ValueError("grouped conv: members must share strides")
     check(L.lib().icm_conv_run_grouped(arr, n, tape.st), "conv_run_grouped")
+    if e0 is not None:
+        N, _, H, W = xs[0].shape
+        px = H * W if transposed else OH * OW
+        _prof_end(e0, _conv_label(tag, transposed, KH, stride, Cin, Cout, H, W, N, n),
+                  2.0 * n * N * Cin * Cout * KH * KW * px)
 
 
 MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_igemm.hip
@@ -603,7 +674,7 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
             epi_b = EPI_RES if rgs is not None else EPI_NONE
         conv_launch_grouped(tape, dys, wpb, None, gxs, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=1, pad=pad,
                             transposed=1, OH=H, OW=W, epi=epi_b,
-                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, ress=rgs, accum=acc0)
+                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, ress=rgs, accum=acc0, tag="dgrad")
         if shared:
             for v, g in zip(xvs, gxs):
                 accumulate(tape, v.t, g)
@@ -625,7 +696,7 @@ def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> to
     y = new(x)
     nrm = new(x) if tape.need_grad else None
     conv_launch(tape, x, wp, beta_eff, y, Cin=Cc, Cout=Cc, KH=1, KW=1, stride=1, pad=0, transposed=0, OH=H, OW=W,
-                pro_act=ACT_SQUARE, epi=EPI_IGDN if inverse else EPI_GDN, aux=x, y2=nrm)
+                pro_act=ACT_SQUARE, epi=EPI_IGDN if inverse else EPI_GDN, aux=x, y2=nrm, tag="fwd(gdn)")
     if not tape.need_grad:
         return y
 
@@ -641,7 +712,7 @@ def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> to
               "gdn_bwd_pre")
         if tape.wants(beta):
             de = torch.empty_like(beta)
-            check(L.lib().icm_channel_sum(ptr(dn), bs(dn), N, Cc, H * W, ptr(de), 0, tape.st), "channel_sum")
+            channel_sum(tape, dn, de, 0)
             gb_, acc = tape.grad_for_write(beta)
             check(L.lib().icm_nonneg_bwd(ptr(beta), ptr(de), ptr(gb_), Cc, bound_b, acc, tape.st), "nonneg_bwd")
         if tape.wants(gamma):
@@ -653,7 +724,7 @@ def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> to
             gx, acc = tape.grad_for_write(x)
             wpt = tape.pack(gamma, Cc, Cc, 1, 1, 0, 0, 1, 0, nonneg=1, bound=bound_g, ped=PEDESTAL)
             conv_launch(tape, dn, wpt, None, gx, Cin=Cc, Cout=Cc, KH=1, KW=1, stride=1, pad=0, transposed=0, OH=H,
-                        OW=W, epi=EPI_AXPY2, aux=x, aux2=t1, accum=acc)
+                        OW=W, epi=EPI_AXPY2, aux=x, aux2=t1, accum=acc, tag="dgrad(gdn)")
 
     tape.bw.append(bwd)
     return y
@@ -687,7 +758,9 @@ def window_msa_core(tape, qkv, table, C_, heads, ws, shift) -> torch.Tensor:
     (win_attention.py:84-115 / stf.py:95-121; roll + window_partition + mask are address arithmetic)."""
     N, _, H, W = qkv.shape
     o = torch.empty((N, C_, H, W), dtype=torch.float32, device=qkv.device)
+    e0 = _prof_begin()
     check(L.lib().icm_winattn_fwd(ptr(qkv), ptr(table), ptr(o), N, C_, H, W, heads, ws, shift, tape.st), "winattn_fwd")
+    _prof_end(e0, f"winattn fwd dim{C_} ws{ws} @{H}x{W} n{N}", 4.0 * N * H * W * ws * ws * C_)
     if tape.need_grad:
         def bwd():
             do = tape.grad_of(o)
@@ -696,10 +769,12 @@ def window_msa_core(tape, qkv, table, C_, heads, ws, shift) -> torch.Tensor:
             dqkv, acc = tape.grad_for_write(qkv)
             assert acc == 0
             gt, acct = tape.grad_for_write(table)
-            if not acct:
-                check(L.lib().icm_fill(ptr(gt), gt.numel(), 0.0, tape.st), "fill")
-            check(L.lib().icm_winattn_bwd(ptr(qkv), ptr(table), ptr(do), ptr(dqkv), ptr(gt), N, C_, H, W, heads, ws,
-                                          shift, tape.st), "winattn_bwd")
+            nws = L.lib().icm_winattn_bwd_workspace_floats(N, C_, H, W, heads, ws)
+            wsp = tape.red_ws(nws, qkv.device)
+            e0 = _prof_begin()
+            check(L.lib().icm_winattn_bwd(ptr(qkv), ptr(table), ptr(do), ptr(dqkv), ptr(gt), acct, ptr(wsp), wsp.numel(),
+                                          N, C_, H, W, heads, ws, shift, tape.st), "winattn_bwd")
+            _prof_end(e0, f"winattn bwd dim{C_} ws{ws} @{H}x{W} n{N}", 8.0 * N * H * W * ws * ws * C_)
         tape.bw.append(bwd)
     return o
 
@@ -746,9 +821,10 @@ def layernorm(tape, x, gamma, beta) -> torch.Tensor:
             if tape.wants(x):
                 rg = tape.take_res_grad(x, False)   # x + f(LN(x)): the identity-path term rides on this pass
                 dx, ax = tape.grad_for_write(x)
+            wsp = tape.red_ws(2 * (2048 + Cc), x.device)
             check(L.lib().icm_layernorm_bwd(ptr(x), bs(x), ptr(dy), bs(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
-                                            bs(dx), ptr(gg), ptr(gb_), N, Cc, HW, ax, ap, ptr(rg), bs(rg), tape.st),
-                  "layernorm_bwd")
+                                            bs(dx), ptr(gg), ptr(gb_), N, Cc, HW, ax, ap, ptr(rg), bs(rg), ptr(wsp),
+                                            wsp.numel(), tape.st), "layernorm_bwd")
         tape.bw.append(bwd)
     return y
 

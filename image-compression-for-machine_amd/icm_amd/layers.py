@@ -37,13 +37,28 @@ def run_module(mod: nn.Module, fn, *inputs):
     return E.tape_function(runner, [*inputs, *params])
 
 
+def _square(mod, *names):
+    """the HIP kernels take one stride / padding for both axes: refuse anything else instead of silently using [0]"""
+    out = []
+    for n in names:
+        v = getattr(mod, n)
+        if isinstance(v, (tuple, list)):
+            if len(set(v)) != 1:
+                raise NotImplementedError(f"icm {type(mod).__name__}: asymmetric {n} {tuple(v)}")
+            v = v[0]
+        out.append(int(v))
+    return out
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameter holder whose forward is the implicit-GEMM HIP kernel (models/utils.py:114-121)."""
 
     def forward(self, x):
-        if self.padding_mode != "zeros" or self.groups != 1 or self.dilation != (1, 1):
+        if self.padding_mode != "zeros" or self.groups != 1 or tuple(self.dilation) != (1, 1):
             raise NotImplementedError("icm Conv2d: only dense zero-padded convolutions")
-        s, p = self.stride[0], self.padding[0]
+        if self.kernel_size[0] != self.kernel_size[1]:
+            raise NotImplementedError("icm Conv2d: square kernels only")
+        s, p = _square(self, "stride", "padding")
         return run_module(self, lambda tape, P, t: (E.conv2d(tape, VT(t), P["weight"], P.get("bias"), stride=s, pad=p),),
                           x.contiguous())[0]
 
@@ -52,7 +67,11 @@ class ConvTranspose2d(nn.ConvTranspose2d):
     """nn.ConvTranspose2d parameter holder on the HIP kernel (models/utils.py:124-132)."""
 
     def forward(self, x):
-        s, p, op = self.stride[0], self.padding[0], self.output_padding[0]
+        if self.padding_mode != "zeros" or self.groups != 1 or tuple(self.dilation) != (1, 1):
+            raise NotImplementedError("icm ConvTranspose2d: only dense zero-padded transposed convolutions")
+        if self.kernel_size[0] != self.kernel_size[1]:
+            raise NotImplementedError("icm ConvTranspose2d: square kernels only")
+        s, p, op = _square(self, "stride", "padding", "output_padding")
         return run_module(self, lambda tape, P, t: (E.conv2d(tape, VT(t), P["weight"], P.get("bias"), stride=s, pad=p,
                                                              transposed=True, output_padding=op),), x.contiguous())[0]
 

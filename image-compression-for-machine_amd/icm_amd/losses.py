@@ -13,9 +13,10 @@ class _RDFn(torch.autograd.Function):
     def forward(ctx, x, x_hat, lik_y, lik_z, lmbda):
         x, x_hat, lik_y, lik_z = (t.contiguous() for t in (x, x_hat, lik_y, lik_z))
         N, _, H, W = x.shape
-        out = torch.zeros(5, dtype=torch.float32, device=x.device)
+        out = torch.empty(5, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.REDUCE_WS_FLOATS, dtype=torch.float32, device=x.device)
         check(L.lib().icm_rd_loss_fwd(ptr(x), ptr(x_hat), x.numel(), ptr(lik_y), lik_y.numel(), ptr(lik_z),
-                                      lik_z.numel(), N * H * W, lmbda, ptr(out), L.stream()), "rd_loss_fwd")
+                                      lik_z.numel(), N * H * W, lmbda, ptr(out), ptr(ws), L.stream()), "rd_loss_fwd")
         ctx.save_for_backward(x, x_hat, lik_y, lik_z)
         ctx.lmbda, ctx.npix = lmbda, N * H * W
         return out[2], out[0], out[1]

@@ -527,12 +527,12 @@ class PatchEmbed(nn.Module):
         self.norm = norm_layer(embed_dim) if norm_layer is not None else None
 
 
-def _draw_drop(rate: float, B: int, device):
+def _draw_drop(rate: float, B: int, device, generator=None):
     """timm DropPath in train mode: per-sample Bernoulli(keep)/keep, one draw per residual branch -> [2, B]"""
     if rate <= 0.0:
         return None
     keep = 1.0 - rate
-    return (torch.rand((2, B), device=device) < keep).to(torch.float32) / keep
+    return (torch.rand((2, B), device=device, generator=generator) < keep).to(torch.float32) / keep
 
 
 class SymmetricalTransFormer(CompressionModel):
@@ -626,10 +626,10 @@ class SymmetricalTransFormer(CompressionModel):
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
 
-    def draw_drops(self, B: int, device) -> Dict[str, torch.Tensor]:
+    def draw_drops(self, B: int, device, generator=None) -> Dict[str, torch.Tensor]:
         out = {}
         for k, r in stf_drop_path_rates(self.drop_path_rate).items():
-            d = _draw_drop(r, B, device)
+            d = _draw_drop(r, B, device, generator)
             if d is not None:
                 out[k] = d
         return out

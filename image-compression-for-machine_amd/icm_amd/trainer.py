@@ -136,16 +136,26 @@ class GradReducer:
 
 class Trainer:
     def __init__(self, model, lr: float = 1e-4, aux_lr: float = 1e-4, lmbda: float = 0.0067,
-                 clip_max_norm: float = 1.0, device="cuda:0", group=None):
+                 clip_max_norm: float = 1.0, device="cuda:0", group=None, seed: int = 0):
         self.model = model.to(device).train()
         self.device = torch.device(device)
         self.flat = FlatParams(self.model, self.device)
         self.lr, self.aux_lr, self.lmbda, self.clip = lr, aux_lr, lmbda, clip_max_norm
         self.reducer = GradReducer(self.flat.g, self.flat.bucket_ranges, group)
         self.world = self.reducer.world
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # replicas start from rank 0's parameters (what DistributedDataParallel does at construction) ...
+        if self.world > 1:
+            for buf in (self.flat.p, self.flat.ap):
+                _broadcast0(buf, group)
+        # ... but draw their OWN quantisation noise / DropPath masks: one generator per rank, seeded seed + rank
+        # (identical noise on every rank would correlate the shards' gradients)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) + self.rank)
         self.step_no = 0
         self.names = [n for n, _ in self.flat.main] + [n for n, _ in self.flat.aux]
         self.scal = torch.zeros(8, dtype=torch.float32, device=self.device)  # [0:5] rd loss, [5] sqnorm, [6] aux
+        self.red_ws = torch.zeros(L.REDUCE_WS_FLOATS, dtype=torch.float32, device=self.device)  # fixed-order partial sums
         self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._side_ws = None
         import os as _os
@@ -172,8 +182,9 @@ class Trainer:
         self.step_no += 1
         B, _, H, W = x.shape
         if noise is None:
-            nz = torch.rand((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev) - 0.5
-            ny = torch.rand((B, self.lat_ch, H // 16, W // 16), dtype=torch.float32, device=dev) - 0.5
+            nz = torch.rand((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev, generator=self.gen) - 0.5
+            ny = torch.rand((B, self.lat_ch, H // 16, W // 16), dtype=torch.float32, device=dev,
+                            generator=self.gen) - 0.5
         else:
             nz, ny = noise["z"].to(dev).contiguous(), noise["y"].to(dev).contiguous()
         P = f.views
@@ -197,15 +208,14 @@ class Trainer:
         marks = {}
         if self.is_stf:
             if drops is None:   # stochastic depth, drawn per step like timm's DropPath (stf.py:145)
-                drops = self.model.draw_drops(B, dev)
+                drops = self.model.draw_drops(B, dev, generator=self.gen)
             drops = {k: v.to(dev, torch.float32).contiguous() for k, v in drops.items()}
             x_hat, y_lik, z_lik = stf_forward(tape, P, x, nz, ny, drops, bucket_marks=marks)
         else:
             x_hat, y_lik, z_lik = wacnn_forward(tape, P, x, nz, ny, bucket_marks=marks)
         # ---- R-D loss forward + seeds (train.py:53-76)
-        self.scal.zero_()
         check(lib.icm_rd_loss_fwd(ptr(x), ptr(x_hat), x.numel(), ptr(y_lik), y_lik.numel(), ptr(z_lik), z_lik.numel(),
-                                  B * H * W, self.lmbda, ptr(self.scal), st), "rd_loss_fwd")
+                                  B * H * W, self.lmbda, ptr(self.scal), ptr(self.red_ws), st), "rd_loss_fwd")
         dxh, dly, dlz = E.new(x_hat), E.new(y_lik), E.new(z_lik)
         check(lib.icm_rd_loss_bwd(ptr(x), ptr(x_hat), x.numel(), ptr(y_lik), y_lik.numel(), ptr(z_lik), z_lik.numel(),
                                   B * H * W, self.lmbda, 1.0, ptr(dxh), ptr(dly), ptr(dlz), st), "rd_loss_bwd")
@@ -239,7 +249,7 @@ class Trainer:
         # ---- clip (global L2 norm of the averaged gradients) + Adam, fused over the flat buffers
         gscale = 1.0 / self.world
         sq = self.scal[5:6]
-        check(lib.icm_grad_sqnorm(ptr(f.g), f.n_main, ptr(sq), st), "grad_sqnorm")
+        check(lib.icm_grad_sqnorm(ptr(f.g), f.n_main, ptr(sq), ptr(self.red_ws), st), "grad_sqnorm")
         check(lib.icm_adam_step(ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.v), f.n_main, self.lr, 0.9, 0.999, 1e-8,
                                 self.step_no, ptr(sq) if self.clip > 0 else 0, float(self.clip), gscale, st), "adam")
         # ---- aux loss on the UPDATED bottleneck weights, gradient to quantiles only (train.py:212-214)
@@ -248,7 +258,18 @@ class Trainer:
         check(lib.icm_eb_aux_loss(C.byref(prm), ptr(self.scal[6:7]), ptr(f.ag), 192, t, st), "eb_aux")
         check(lib.icm_adam_step(ptr(f.ap), ptr(f.ag), ptr(f.am), ptr(f.av), f.ap.numel(), self.aux_lr, 0.9, 0.999, 1e-8,
                                 self.step_no, 0, 0.0, 1.0, st), "adam_aux")
+        E.bump_weight_generation()   # packed-weight caches keyed before this step are stale now
         return self.scal
+
+
+def _broadcast0(t: torch.Tensor, group=None):
+    """in-place broadcast from rank 0 (RCCL for device tensors; through the host for the gloo rehearsal path)"""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.broadcast(h, src=0, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=0, group=group)
 
 
 def math_target(tail_mass: float = 1e-9) -> float:

@@ -9,7 +9,10 @@
  *     stride of every tensor is explicit (in floats) so channel-slices of a larger buffer
  *     (torch.cat / chunk in compressai/models/cnn.py:157-183) are addressed without copies;
  *   - `stream` is a hipStream_t; kernels are enqueued on it; nothing allocates, frees or
- *     synchronises (graph-capture safe);
+ *     synchronises (graph-capture safe); scratch memory is always a caller-owned workspace;
+ *   - every reduction (bias / LayerNorm / table gradients, loss sums, gradient norm, split-K
+ *     weight gradients) adds its partial sums in a FIXED order -- no float atomics -- so equal inputs
+ *     give bit-identical outputs on every rank of a data-parallel job;
  *   - return value: 0 = ok, ICM_ERR_* otherwise (icm_strerror()).
  */
 #ifndef ICM_HIP_H
@@ -121,8 +124,10 @@ int icm_conv_wgrad(const icm_wgrad_args* a, void* stream);
  * backward and issued together); every arr[i].ws is that problem's own workspace */
 int icm_conv_wgrad_grouped(const icm_wgrad_args* arr, int n, void* stream);
 
-/* out[c] (+)= sum_{n,p} x[n,c,p]   (bias gradients; GDN d_beta) */
-int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, void* stream);
+/* out[c] (+)= sum_{n,p} x[n,c,p]   (bias gradients; GDN d_beta).  ws (optional, ws_floats >= 32*C for full
+ * parallelism): partial sums of the pixel splits, added in split order; ws = NULL -> one workgroup per channel */
+int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* out, int accum, float* ws,
+                    int64_t ws_floats, void* stream);
 
 /* ---- GDN helpers (layers/gdn.py:62-75, ops/parametrizers.py:46-49, ops/bound_ops.py:25-27) ---- */
 int icm_nonneg_fwd(const float* p, float* out, int64_t n, float bound, float pedestal, void* stream);
@@ -160,6 +165,7 @@ int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const fl
 int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_bs, const float* gamma,
                       const float* mean, const float* rstd, float* dx, int64_t dx_bs, float* dgamma, float* dbeta,
                       int N, int C, int HW, int accum_dx, int accum_params, const float* dx_extra, int64_t dx_extra_bs,
+                      float* ws, int64_t ws_floats /* optional split partials of dgamma / dbeta: 2*(2048 + C) floats */,
                       void* stream);
 /* PatchMerging's 2x2 gather (stf.py:224-228): dst[n][k*C+c][y][x] = src[n][c][2y+(k&1)][2x+(k>>1)]; inverse=1 scatters
  * a [N,4C,H/2,W/2] gradient back into [N,C,H,W] */
@@ -186,9 +192,12 @@ int icm_col2im(const float* cols, const float* bias, float* out, int N, int C, i
  * table: relative_position_bias_table [(2ws-1)^2][heads]. */
 int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W,
                     int heads, int ws, int shift, void* stream);
-/* dqkv = gradient wrt qkv (overwritten), dtable (+)= gradient wrt table (must be zeroed by caller if !accum) */
+/* dqkv = gradient wrt qkv (overwritten); dtable (+)= gradient wrt table (accum_table = 0 overwrites).  wsp: workspace
+ * of icm_winattn_bwd_workspace_floats() floats holding one partial table per (window, head), reduced in window order */
+int64_t icm_winattn_bwd_workspace_floats(int N, int C, int H, int W, int heads, int ws);
 int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable,
-                    int N, int C, int H, int W, int heads, int ws, int shift, void* stream);
+                    int accum_table, float* wsp, int64_t ws_floats, int N, int C, int H, int W, int heads, int ws,
+                    int shift, void* stream);
 
 /* ---- EntropyBottleneck (entropy_models.py:395-433,446-489) ---------------------------------
  * params: the 13 tensors concatenated per channel is NOT required; pointers are passed separately.
@@ -226,23 +235,33 @@ int icm_gc_likelihood_ste_bwd(const float* y, int64_t y_bs, const float* mu, int
                               float lik_bound, int accum_dy, void* stream);
 
 /* ---- R-D loss (train.py:53-61, train_czigzag.py:63,71) --------------------------------------
- * out[0]=bpp, out[1]=mse, out[2]=loss, out[3]=sum log(lik_y), out[4]=sum log(lik_z); out must be
- * zeroed by the caller (5 floats); two launches (reduce, finish). */
+ * out[0]=bpp, out[1]=mse, out[2]=loss, out[3]=sum log(lik_y), out[4]=sum log(lik_z) (5 floats, overwritten);
+ * ws: ICM_REDUCE_WS_FLOATS floats of scratch (per-workgroup partial sums, added in workgroup order). */
+#define ICM_REDUCE_WS_FLOATS 8192
 int icm_rd_loss_fwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
-                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, void* stream);
+                    const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, float* ws,
+                    void* stream);
 /* dx_hat = gscale * lmbda*255^2*2*(x_hat-x)/n ; dlik = gscale * -1/(lik*ln2*num_pixels) */
 int icm_rd_loss_bwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
                     const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float gscale,
                     float* dx_hat, float* dlik_y, float* dlik_z, void* stream);
 
 /* ---- optimiser (train.py:105-169,199-214) ---------------------------------------------------- */
-/* out[0] += sum g^2 (caller zeroes) */
-int icm_grad_sqnorm(const float* g, int64_t n, float* out, void* stream);
+/* out[0] = sum g^2; ws: ICM_REDUCE_WS_FLOATS floats of scratch (fixed-order two-stage sum: every rank of a
+ * data-parallel job derives the same clip coefficient from the same all-reduced gradient) */
+int icm_grad_sqnorm(const float* g, int64_t n, float* out, float* ws, void* stream);
 /* Adam step with fused clip: coef = min(1, max_norm/(sqrt(*sqnorm)+1e-6)) if sqnorm!=NULL else 1;
  * g is scaled by gscale (1/world_size) then coef; torch.optim.Adam defaults semantics. */
 int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream);
 int icm_fill(float* p, int64_t n, float v, void* stream);
+
+/* ---- test hooks (process-global; used by the parity tests and tools/tune_conv.py only) ----------------------
+ * force the implicit-GEMM tile configuration (index into the kernel table, -1 = automatic) / the weight-gradient
+ * kernel variant (0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4>, 3 = <3,3,9> wave-split; -1 = automatic) and its XCD-aware
+ * workgroup order (0 / 1, -1 = automatic) */
+void icm_debug_force_conv_cfg(int idx);
+void icm_debug_force_wgrad_cfg(int variant, int xcd_order);
 
 #ifdef __cplusplus
 }

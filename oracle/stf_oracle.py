@@ -186,14 +186,15 @@ def synthesis(y_hat: Tensor, sd, drops=None) -> Tensor:
 
 
 def stf_forward(sd: Dict[str, Tensor], x: Tensor, noise: Optional[Dict[str, Tensor]] = None,
-                drops: Optional[Dict[str, Tensor]] = None, keep: bool = False) -> Dict:
+                drops: Optional[Dict[str, Tensor]] = None, keep: bool = False,
+                round_override: Optional[Dict[str, Tensor]] = None) -> Dict:
     """SymmetricalTransFormer.forward (stf.py:582-645).
 
     noise: None -> eval quantisation; else {"z": [B,192,h/4,w/4], "y": [B,384,h,w]} U(-1/2,1/2) samples.
     drops: None -> no stochastic depth (eval); else {"<layer>.blocks.<j>": [2,B] scales} as drawn by
     timm's DropPath in train mode (mask / keep_prob)."""
     y = analysis(x, sd, drops)
-    y_hat, y_lik, z_lik, dbg = O.hyper_slices(y, sd, noise, NUM_SLICES, MAX_SUPPORT)
+    y_hat, y_lik, z_lik, dbg = O.hyper_slices(y, sd, noise, NUM_SLICES, MAX_SUPPORT, round_override)
     x_hat = synthesis(y_hat, sd, drops)
     out = {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
     if keep:

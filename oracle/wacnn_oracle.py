@@ -281,14 +281,25 @@ def g_s(y_hat, sd):
     return deconv(x, sd, "g_s.8")
 
 
+def ste_round_as(x: Tensor, r: Optional[Tensor]) -> Tensor:
+    """ste_round with the rounding DECISION taken from ``r`` (integers of x's shape) when given: same value and
+    gradient structure, but a latent that sits within float noise of a half-integer rounds the way the checked
+    implementation rounded it, so the comparison downstream stays smooth (flips are counted separately)."""
+    if r is None:
+        return ste_round(x)
+    return (r.to(x.dtype) - x).detach() + x
+
+
 def hyper_slices(y: Tensor, sd: Dict[str, Tensor], noise: Optional[Dict[str, Tensor]], num_slices: int,
-                 max_support: int):
+                 max_support: int, round_override: Optional[Dict[str, Tensor]] = None):
     """Hyperprior + channel-conditional slice loop shared by the cnn and stf models
-    (cnn.py:144-183 == stf.py:596-637).  Returns (y_hat, y_lik, z_lik, dbg)."""
+    (cnn.py:144-183 == stf.py:596-637).  Returns (y_hat, y_lik, z_lik, dbg).
+    round_override (tests only): {"y": round(y - mu) [B,M,H,W], "z": round(z - med)} decisions to adopt."""
+    ro = round_override or {}
     z = h_a(y, sd)
     _, z_lik = eb_likelihood(z, sd, "entropy_bottleneck", None if noise is None else noise["z"])
     med = sd["entropy_bottleneck.quantiles"][:, :, 1:2].reshape(1, -1, 1, 1)
-    z_hat = ste_round(z - med) + med
+    z_hat = ste_round_as(z - med, ro.get("z")) + med
     lat_scales = h_s(z_hat, sd, "h_scale_s")
     lat_means = h_s(z_hat, sd, "h_mean_s")
     y_slices = y.chunk(num_slices, 1)
@@ -304,7 +315,8 @@ def hyper_slices(y: Tensor, sd: Dict[str, Tensor], noise: Optional[Dict[str, Ten
         sc = sc[:, :, :y.shape[2], :y.shape[3]]
         _, lik = gaussian_likelihood(ys, sc, mu, None if noise is None else n_slices[i])
         liks.append(lik)
-        yh = ste_round(ys - mu) + mu
+        ry = ro["y"].chunk(num_slices, 1)[i] if "y" in ro else None
+        yh = ste_round_as(ys - mu, ry) + mu
         lrp = _seq_convs(torch.cat([mean_sup, yh], 1), sd, f"lrp_transforms.{i}", (0, 2, 4, 6, 8))
         yh = yh + 0.5 * torch.tanh(lrp)
         y_hat_slices.append(yh)
@@ -318,7 +330,7 @@ def hyper_slices(y: Tensor, sd: Dict[str, Tensor], noise: Optional[Dict[str, Ten
 
 
 def wacnn_forward(sd: Dict[str, Tensor], x: Tensor, noise: Optional[Dict[str, Tensor]] = None,
-                  keep: bool = False) -> Dict:
+                  keep: bool = False, round_override: Optional[Dict[str, Tensor]] = None) -> Dict:
     """WACNN.forward. compressai/models/cnn.py:141-189.
 
     noise: None -> eval-mode quantisation.  Else {"z": [B,192,h,w], "y": [B,320,H,W]} uniform
@@ -326,7 +338,7 @@ def wacnn_forward(sd: Dict[str, Tensor], x: Tensor, noise: Optional[Dict[str, Te
     (entropy_models.py:131-135) -- only the *likelihood* inputs are noised; z_hat / y_hat use
     ste_round in both modes (cnn.py:150-152,173)."""
     y = g_a(x, sd)
-    y_hat, y_lik, z_lik, dbg = hyper_slices(y, sd, noise, NUM_SLICES, MAX_SUPPORT)
+    y_hat, y_lik, z_lik, dbg = hyper_slices(y, sd, noise, NUM_SLICES, MAX_SUPPORT, round_override)
     x_hat = g_s(y_hat, sd)
     out = {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
     if keep:

@@ -74,3 +74,79 @@ def test_flat_buckets_and_allreduce_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _step_worker(rank, world, port, q):
+    """a full Trainer.step per rank on CPU with kernel launches stubbed (host logic + gloo collectives are real)"""
+    for p in (ROOT, os.path.join(ROOT, "image-compression-for-machine_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from icm_amd import _lib, engine as E
+        real = _lib.lib()
+
+        class Fake:
+            def __getattr__(self, name):
+                if name in ("icm_packed_weight_floats", "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped",
+                            "icm_winattn_bwd_workspace_floats", "icm_strerror"):
+                    return getattr(real, name)
+                return lambda *a: 0
+        fake = Fake()
+        _lib.lib = lambda: fake
+        _lib.stream = lambda: 0
+
+        def bs(t):
+            if t is None:
+                return 0
+            return t.stride()[0] if t.dim() == 4 else t[0].numel()
+        _lib.bs = bs
+        E.bs = bs
+        from icm_amd.trainer import Trainer
+        from icm_amd.zoo import models
+        torch.manual_seed(100 + rank)          # ranks start from DIFFERENT weights ...
+        tr = Trainer(models["cnn"](), device="cpu", seed=5)
+        assert tr.world == world and tr.rank == rank and tr.side is None
+        ref = [torch.zeros_like(tr.flat.p) for _ in range(world)]
+        dist.all_gather(ref, tr.flat.p)
+        assert torch.equal(ref[0], ref[1]), "parameters were not broadcast from rank 0"   # ... and end up with rank 0's
+        fired = []
+        launch = tr.reducer.launch
+
+        def spy(b):
+            # stand-in for the kernels: this rank's gradient of bucket b is (rank + 1) everywhere
+            a, e = tr.flat.bucket_ranges[b]
+            tr.flat.g[a:e] = float(rank + 1)
+            fired.append(b)
+            launch(b)
+        tr.reducer.launch = spy
+        n1 = torch.rand(1, generator=tr.gen)
+        tr.step(torch.rand(2, 3, 64, 64))
+        assert fired == [0, 1, 2, 3], fired
+        # every bucket was sum-all-reduced: 1 + 2 on every element, on both ranks
+        assert torch.equal(tr.flat.g, torch.full_like(tr.flat.g, 3.0))
+        # per-rank noise generators differ (seed + rank)
+        ns = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(ns, n1)
+        assert ns[0].item() != ns[1].item()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_step_world2_dry_run():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -362,13 +362,13 @@ def test_rd_loss_and_adam():
     m = torch.zeros(n)
     v = torch.zeros(n)
     pg, gg_, mg, vg = (t.clone().to(d) for t in (p, g, m, v))
-    sq = torch.zeros(1, device=d)
+    sq = torch.full((1,), 123.0, device=d)   # overwritten, not accumulated
+    rws = torch.empty(L.REDUCE_WS_FLOATS, device=d)
     for step in (1, 2, 3):
         gs = [g.clone()]
         total = O.clip_grad_norm_(gs, 1.0)
         O.adam_step(p, gs[0], m, v, step, 1e-4)
-        sq.zero_()
-        L.check(L.lib().icm_grad_sqnorm(L.ptr(gg_), n, L.ptr(sq), L.stream()))
+        L.check(L.lib().icm_grad_sqnorm(L.ptr(gg_), n, L.ptr(sq), L.ptr(rws), L.stream()))
         assert abs(math.sqrt(sq.item()) - total.item()) <= 1e-5 * total.item()
         L.check(L.lib().icm_adam_step(L.ptr(pg), L.ptr(gg_), L.ptr(mg), L.ptr(vg), n, 1e-4, 0.9, 0.999, 1e-8, step,
                                       L.ptr(sq), 1.0, 1.0, L.stream()))
@@ -470,3 +470,146 @@ def test_conv_group_shared_input_and_lrp_tail_vs_singles():
     # and against torch for member 0: y = aux + 0.5 * tanh(conv(x))
     ref = auxs[0].cpu() + 0.5 * torch.tanh(F.conv2d(x.cpu(), ws[0].cpu(), bs_[0].cpu(), padding=1))
     close(ya[0], ref, what="lrp tail vs torch")
+
+
+# ------------------------------------------------------------------------------------------ wgrad kernel variants
+def _wgrad_ref(x, w, b, g, k, s, tr):
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    if tr:
+        yr = F.conv_transpose2d(xr, wr, br, stride=s, padding=k // 2, output_padding=s - 1)
+    else:
+        yr = F.conv2d(xr, wr, br, stride=s, padding=k // 2)
+    return torch.autograd.grad(yr, [wr, br], g)
+
+
+WG_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, transposed, variants to force
+    ("wg_c5s2", 3, 40, 36, 20, 72, 5, 2, False, (0, 1, 3)),   # <4,4,4> needs > 160 KB of LDS for a 5x5 stride-2 patch
+    ("wg_t5s2", 2, 48, 10, 12, 40, 5, 2, True, (0, 1)),
+    ("wg_c3s1", 3, 48, 20, 12, 80, 3, 1, False, (0, 1, 2, 3)),
+    ("wg_c1_96_192", 2, 96, 16, 16, 192, 1, 1, False, (0, 1, 2, 3)),
+    ("wg_c1_130_70", 3, 130, 12, 20, 70, 1, 1, False, (0, 1, 2, 3)),
+    ("wg_c3_tiny", 4, 24, 4, 4, 48, 3, 1, False, (0, 1, 2, 3)),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad_every_variant(case):
+    """each of wgrad_kernel<2,1,7>, <2,2,9>, <4,4,4> and <3,3,9,wave-split>, with the plain and the XCD-aware
+    workgroup order, against torch.autograd.grad of F.conv2d / F.conv_transpose2d on CPU (weight AND fused bias grads)"""
+    from icm_amd import _lib, layers
+    name, N, Cin, H, Wd, Cout, k, s, tr, variants = case
+    d = dev()
+    lib = _lib.lib()
+    m = layers.deconv(Cin, Cout, kernel_size=k, stride=s) if tr else layers.Conv2d(Cin, Cout, k, stride=s, padding=k // 2)
+    w = U(name + ".w", m.weight.shape, -0.2, 0.2)
+    b = U(name + ".b", m.bias.shape, -0.5, 0.5)
+    x = U(name + ".x", (N, Cin, H, Wd), -1.0, 1.0)
+    with torch.no_grad():
+        yshape = (F.conv_transpose2d(x, w, b, stride=s, padding=k // 2, output_padding=s - 1) if tr
+                  else F.conv2d(x, w, b, stride=s, padding=k // 2)).shape
+    g = U(name + ".g", yshape, -1.0, 1.0)
+    gwr, gbr = _wgrad_ref(x, w, b, g, k, s, tr)
+    m = m.to(d)
+    with torch.no_grad():
+        m.weight.copy_(w)
+        m.bias.copy_(b)
+    try:
+        for v in variants:
+            for xcd in (0, 1):
+                lib.icm_debug_force_wgrad_cfg(v, xcd)
+                y = m(x.to(d))
+                gw, gb = torch.autograd.grad(y, [m.weight, m.bias], g.to(d))
+                close(gw, gwr, what=f"dw variant {v} xcd {xcd}")
+                close(gb, gbr, what=f"db variant {v} xcd {xcd}")
+    finally:
+        lib.icm_debug_force_wgrad_cfg(-1, -1)
+
+
+# ------------------------------------------------------------------------------------------ bench-size launches
+BIG_CASES = [
+    # the shapes bench.py's step is made of, at batch 16: name, N, Cin, H, W, Cout, k, stride, transposed
+    ("g_a.2", 16, 192, 128, 128, 192, 5, 2, False),
+    ("g_s.6", 16, 192, 64, 64, 192, 5, 2, True),
+    ("g_a.7", 16, 192, 32, 32, 320, 5, 2, False),
+    ("RU c1", 16, 192, 64, 64, 96, 1, 1, False),
+    ("RU c3", 16, 96, 64, 64, 96, 3, 1, False),
+    ("cc.0", 16, 480, 16, 16, 224, 3, 1, False),
+    ("cc.6", 16, 128, 16, 16, 64, 3, 1, False),
+    ("cc.8", 16, 64, 16, 16, 32, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", BIG_CASES, ids=[c[0] for c in BIG_CASES])
+def test_conv_bench_size_vs_torch(case):
+    """forward, input gradient, weight and bias gradient of the bench's own launch shapes (B=16: the single-pass
+    tilings, XCD-aware orders and pixel-split counts chosen there) against F.conv2d / F.conv_transpose2d on CPU"""
+    test_conv_fwd_bwd(case)
+
+
+def test_conv_group_bench_size_vs_torch():
+    """a 10-member grouped launch of the slice-chain head (5 mean + 5 scale chains of the independent tail slices share
+    two inputs) at batch 16: every member's forward, shared-input gradient, weight and bias gradient vs torch"""
+    from icm_amd import engine as E
+    from icm_amd.engine import VT
+    d = dev()
+    N, Cin, Cout, H = 16, 480, 224, 16
+    xs = [U(f"grp.x{i}", (N, Cin, H, H), -1.0, 1.0) for i in range(2)]
+    ws = [U(f"grp.w{i}", (Cout, Cin, 3, 3), -0.05, 0.05) for i in range(10)]
+    bs_ = [U(f"grp.b{i}", (Cout,), -0.5, 0.5) for i in range(10)]
+    gs = [U(f"grp.g{i}", (N, Cout, H, H), -1.0, 1.0) for i in range(10)]
+    xd = [t.to(d) for t in xs]
+    wd = [t.to(d) for t in ws]
+    bd = [t.to(d) for t in bs_]
+    tape = E.Tape(need_grad=True)
+    ys = E.conv2d_group(tape, [VT(xd[i // 5]) for i in range(10)], wd, bd, pad=1)
+    for y, g in zip(ys, gs):
+        tape.bind_grad(y, g.to(d), True)
+    tape.backward()
+    torch.cuda.synchronize()
+    gx_ref = [torch.zeros_like(xs[0]), torch.zeros_like(xs[1])]
+    for i in range(10):
+        xr, wr, br = xs[i // 5].clone().requires_grad_(True), ws[i].clone().requires_grad_(True), bs_[i].clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, br, padding=1)
+        gx, gw, gb = torch.autograd.grad(yr, [xr, wr, br], gs[i])
+        gx_ref[i // 5] += gx
+        close(ys[i], yr, what=f"y{i}")
+        close(tape.grad_of(wd[i]), gw, what=f"dw{i}")
+        close(tape.grad_of(bd[i]), gb, what=f"db{i}")
+    for j in range(2):
+        close(tape.grad_of(xd[j]), gx_ref[j], what=f"dx{j}")
+
+
+def test_gate_golden(golden_dir):
+    """Win_noShift_Attention against the fixture produced by the REAL reference module (gate_d64_ws8.npz)"""
+    from icm_amd import layers
+    tag, dim, ws, shift = "gate_d64_ws8", 64, 8, 4
+    f = load(golden_dir, tag)
+    d = dev()
+    m = layers.Win_noShift_Attention(dim=dim, num_heads=8, window_size=ws, shift_size=shift)
+    sd = dict(m.state_dict())
+    for k, v in m.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        key = tag + "." + k
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "relative_position_bias_table":
+            sd[k] = U(key, v.shape, -0.5, 0.5)
+        elif leaf == "weight":
+            bnd = 1.0 / math.sqrt(int(np.prod(v.shape[1:])))
+            sd[k] = U(key, v.shape, -bnd, bnd) * 1.7
+        else:
+            sd[k] = U(key, v.shape, -0.1, 0.1)
+    m.load_state_dict(sd)
+    m = m.to(d)
+    x = f["x"].to(d).requires_grad_(True)
+    y = m(x)
+    close(y, f["y"], what="y")
+    names = [str(n) for n in f["grad_names"]]
+    P = dict(m.named_parameters())
+    gs = torch.autograd.grad(y, [x] + [P[n] for n in names], f["g"].to(d))
+    close(gs[0], f["gx"], 5e-5, what="gx")
+    gn = torch.stack([t.norm() for t in gs[1:]]).cpu()
+    close(gn, f["grad_norms"], 5e-5, what="grad norms")
+    close(gs[1 + names.index("conv_a.0.conv.0.weight")], f["g_first_conv_w"], 5e-5, what="g_first_conv_w")
+    close(gs[1 + names.index("conv_b.4.bias")], f["g_last_conv_b"], 5e-5, what="g_last_conv_b")

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import stf_oracle as S
+import _parity as PT
 from oracle import wacnn_oracle as O
 from oracle import weights as W
 
@@ -210,31 +211,34 @@ def test_stf_train_step_grads_vs_reference_fixture(golden_dir, model):
     loss_rel = abs(crit["loss"].item() - f["t_loss"].item()) / f["t_loss"].item()
     xh_rel = rel(out["x_hat"][:, :, 32:64, 64:96], f["t_x_hat_crop"])
     print("train loss rel diff", loss_rel, "x_hat crop rel", xh_rel)
-    assert loss_rel < 5e-3
+    flip_free = xh_rel < 1e-4   # the fixture holds no train-input latents: a flipped latent shows as an x_hat jump
+    assert loss_rel < (5e-5 if flip_free else 5e-3)
     names = [str(n) for n in f["t_grad_names"]]
     P = dict(model.named_parameters())
     got = torch.tensor([0.0 if P[n].grad is None else P[n].grad.double().norm().item() for n in names]).double()
     tot_ref = float(f["t_total_grad_norm"])
     err = (got - f["t_grad_norms"].double()).abs().max().item() / tot_ref
     print("worst per-tensor grad-norm error / total norm:", err)
-    assert err < 2e-2
-    flip_free = xh_rel < 1e-4
+    assert err < (1e-4 if flip_free else 2e-2)
     worst = 0.0
     for k in f:
         if k.startswith("t_g_"):
             r = rel(P[k[4:]].grad, f[k])
             worst = max(worst, r)
             print(f"  grad {k[4:]}: rel {r:.2e}")
-    assert rel(P["entropy_bottleneck._matrix0"].grad, f["t_g_entropy_bottleneck._matrix0"]) < 1e-3
+    assert rel(P["entropy_bottleneck._matrix0"].grad, f["t_g_entropy_bottleneck._matrix0"]) < 2e-4
     assert worst < (2e-4 if flip_free else 5e-2)
     aux = model.aux_loss()
     assert abs(aux.item() - f["t_aux"].item()) <= 1e-5 * f["t_aux"].item()
 
 
 def test_stf_train_grads_vs_oracle_small():
-    """64x64 input, oracle autograd as reference: every parameter gradient"""
+    """64x64 input, oracle autograd as reference: EVERY parameter gradient, unconditionally (the oracle adopts the HIP
+    path's rounding decisions; flips are counted and bounded separately)"""
     from icm_amd.zoo import models
     from icm_amd.losses import RateDistortionLoss
+    from icm_amd.layers import _named
+    from icm_amd.models import stf_forward
     sd = W.make_stf_state_dict()
     B = 2
     x = W._u("stfs.x", (B, 3, 64, 64), 0.0, 1.0)
@@ -243,37 +247,44 @@ def test_stf_train_grads_vs_oracle_small():
     for name, rate in S.drop_path_rates().items():
         if rate > 0:
             drops[name] = (W._u("stfs.dp." + name, (2, B), 0.0, 1.0) < 1.0 - rate).float() / (1.0 - rate)
-    s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd.items()}
-    o = S.stf_forward(s, x, noise, drops)
-    Lr = O.rd_loss(x, o, 0.0067)
-    Lr["loss"].backward()
     net = models["stf"]()
     net.load_state_dict(sd)
     net = net.cuda().train()
+    names_, params_ = _named(net)
+    ro, _ = PT.hip_round_decisions(stf_forward, dict(zip(names_, [p.detach() for p in params_])), x.cuda(),
+                                   noise["z"].cuda(), noise["y"].cuda(),
+                                   drops={k: v.cuda().contiguous() for k, v in drops.items()})
+    s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd.items()}
+    o = S.stf_forward(s, x, noise, drops, keep=True, round_override=ro)
+    Lr = O.rd_loss(x, o, 0.0067)
+    Lr["loss"].backward()
+    fy, fz = PT.count_flips(ro, o["_dbg"], s)
+    print("flips y/z:", fy, fz)
+    assert fy <= PT.near_half(o["_dbg"]) + 2 and fz == 0
     net.inject_noise(noise, drops)
     out = net(x.cuda())
     crit = RateDistortionLoss(0.0067)(out, x.cuda())
     crit["loss"].backward()
     assert abs(crit["bpp_loss"].item() - Lr["bpp_loss"].item()) <= 1e-4 * Lr["bpp_loss"].item()
-    tot = math.sqrt(sum((s[n].grad.double() ** 2).sum().item() for n, _ in net.named_parameters() if s[n].grad is not None))
-    bad = []
-    for n, p in net.named_parameters():
-        gr = s[n].grad if s[n].grad is not None else torch.zeros_like(s[n])
-        gg = p.grad.cpu() if p.grad is not None else torch.zeros_like(gr)
-        e = (gg - gr).double().norm().item() / tot
-        if e > 1e-3:
-            bad.append((n, e))
-    xr = rel(out["x_hat"], o["x_hat"])
-    print("x_hat rel diff", xr, "bad grads:", bad[:8])
-    if xr < 1e-4:   # no rounding flip happened: everything must match tightly
-        assert not bad
+    assert abs(crit["loss"].item() - Lr["loss"].item()) <= 5e-5 * Lr["loss"].item()
+    assert rel(out["x_hat"], o["x_hat"]) < 1e-4
+    names = [n for n, _ in net.named_parameters() if not n.endswith(".quantiles")]
+    hip = {n: p.grad for n, p in net.named_parameters()}
+    ref = {n: s[n].grad for n in names}
+    tot, worst_l2, worst_elem, rows = PT.grad_errors(hip, ref, names)
+    rows.sort(key=lambda r: -r[3])
+    print(f"all {len(rows)} gradients: worst ||d||/total {worst_l2:.2e}, worst element-wise rel {worst_elem:.2e}; "
+          f"top: {[(n, f'{e:.1e}') for n, _, _, e in rows[:4]]}")
+    assert len(rows) == len(names)
+    assert worst_l2 < 1e-4 and worst_elem < 2e-4
 
 
 def test_stf_trainer_step_vs_oracle():
-    """native data-parallel step on the stf model: loss of step 1 and the 2-step parameter update == reference loop
-    semantics (train.py:188-214) evaluated on the oracle with the same injected noise / DropPath scales"""
+    """native data-parallel step on the stf model: loss and the accumulated parameter update of two steps == reference
+    loop semantics (train.py:188-214) evaluated on the oracle with the same injected noise / DropPath scales"""
     from icm_amd.zoo import models
     from icm_amd.trainer import Trainer
+    from icm_amd.models import stf_forward
     sd = W.make_stf_state_dict()
     B = 2
     x = W._u("stft.x", (B, 3, 64, 64), 0.0, 1.0)
@@ -286,37 +297,23 @@ def test_stf_trainer_step_vs_oracle():
             if rate > 0:
                 d[name] = (W._u(f"stft.dp{i}." + name, (2, B), 0.0, 1.0) < 1.0 - rate).float() / (1.0 - rate)
         drops.append(d)
-    s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd.items()}
-    pnames = [k for k, v in s.items() if isinstance(v, torch.Tensor) and v.requires_grad and
-              k.rsplit(".", 1)[-1] not in ("pedestal", "bound", "target", "scale_bound")]
-    main = [n for n in pnames if not n.endswith(".quantiles")]
-    st = {n: (torch.zeros_like(s[n]), torch.zeros_like(s[n])) for n in pnames}
-    ref_losses = []
-    for it in range(2):
-        for n in pnames:
-            s[n].grad = None
-        out = S.stf_forward(s, x, noises[it], drops[it])
-        Lr = O.rd_loss(x, out, 0.0067)
-        Lr["loss"].backward()
-        ref_losses.append(Lr["loss"].item())
-        grads = [s[n].grad if s[n].grad is not None else torch.zeros_like(s[n]) for n in main]
-        O.clip_grad_norm_(grads, 1.0)
-        with torch.no_grad():
-            for n, g in zip(main, grads):
-                O.adam_step(s[n], g, st[n][0], st[n][1], it + 1, 1e-4)
-        aux = O.eb_aux_loss(s)
-        (gq,) = torch.autograd.grad(aux, [s["entropy_bottleneck.quantiles"]])
-        with torch.no_grad():
-            q = "entropy_bottleneck.quantiles"
-            O.adam_step(s[q], gq, st[q][0], st[q][1], it + 1, 1e-4)
+    s, pnames, main, st = PT.trainable(sd)
     net = models["stf"]()
     net.load_state_dict(sd)
     tr = Trainer(net, lr=1e-4, aux_lr=1e-4, lmbda=0.0067, clip_max_norm=1.0, device="cuda:0")
-    losses = [tr.step(x.cuda(), noises[it], drops[it])[2].item() for it in range(2)]
-    print("losses", losses, ref_losses)
-    assert abs(losses[0] - ref_losses[0]) <= 1e-4 * abs(ref_losses[0])
-    P = dict(net.named_parameters())
-    num = sum(((P[n].detach().cpu() - s[n].detach()).double() ** 2).sum().item() for n in pnames)
-    den = sum(((s[n].detach() - sd[n]).double() ** 2).sum().item() for n in pnames)
-    print("relative L2 error of the update:", math.sqrt(num / den))
-    assert math.sqrt(num / den) < 2e-2
+    xg = x.cuda()
+    for it in range(2):
+        dd = {k: v.cuda().contiguous() for k, v in drops[it].items()}
+        ro, _ = PT.hip_round_decisions(stf_forward, tr.params(), xg, noises[it]["z"].cuda(), noises[it]["y"].cuda(), drops=dd)
+        sc = tr.step(xg, noises[it], drops[it]).tolist()
+        Lr = PT.oracle_train_step(S.stf_forward, s, x, noises[it], it + 1, st, pnames, main, drops=drops[it], keep=True,
+                                  round_override=ro)
+        fy, fz = PT.count_flips(ro, Lr["out"]["_dbg"], s)
+        e = abs(sc[2] - Lr["loss"].item()) / abs(Lr["loss"].item())
+        print(f"step {it + 1}: loss {sc[2]:.6f} vs {Lr['loss'].item():.6f} (rel {e:.1e}), flips {fy} {fz}")
+        assert fy <= PT.near_half(Lr["out"]["_dbg"]) + 2 and fz == 0
+        assert e < 5e-5
+        P = dict(net.named_parameters())
+        l2 = PT.update_l2(P, s, sd, pnames)
+        print(f"  relative L2 error of the accumulated update: {l2:.2e}")
+        assert l2 < 5e-4

@@ -175,3 +175,30 @@ def test_wacnn_end_to_end_eval(golden_dir):
     assert abs(L["bpp_loss"].item() - f["bpp"].item()) <= 1e-4 * f["bpp"].item() + 3e-4 * flips
     assert abs(L["mse_loss"].item() - f["mse"].item()) <= 1e-4 * f["mse"].item() + 1e-3 * flips
     assert O.psnr(L["mse_loss"].item()) == pytest.approx(-10 * math.log10(f["mse"].item()), abs=1e-3 + 0.01 * flips)
+
+
+def test_round_override_is_transparent():
+    """tests/_parity.py: an oracle run that ADOPTS rounding decisions equal to its own reproduces the free run bit for
+    bit (values and gradients), and a changed decision moves y_hat by exactly one step"""
+    sd = W.make_wacnn_state_dict()
+    x = W._u("ro.x", (1, 3, 64, 64), 0.0, 1.0)
+    noise = {"z": W._u("ro.nz", (1, 192, 1, 1), -0.5, 0.5), "y": W._u("ro.ny", (1, 320, 4, 4), -0.5, 0.5)}
+
+    def run(ro):
+        s = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and v.numel() else v) for k, v in sd.items()}
+        o = O.wacnn_forward(s, x, noise, keep=True, round_override=ro)
+        O.rd_loss(x, o)["loss"].backward()
+        return o, s
+    o0, s0 = run(None)
+    d = o0["_dbg"]
+    med = sd["entropy_bottleneck.quantiles"][:, :, 1:2].reshape(1, -1, 1, 1)
+    ro = {"y": torch.round(d["y"] - d["mu"]).detach(), "z": torch.round(d["z"] - med).detach()}
+    o1, s1 = run(ro)
+    assert torch.equal(o0["x_hat"], o1["x_hat"]) and torch.equal(o0["likelihoods"]["y"], o1["likelihoods"]["y"])
+    for k in ("g_a.0.weight", "g_s.8.bias", "lrp_transforms.9.8.weight", "h_a.0.weight"):
+        assert torch.equal(s0[k].grad, s1[k].grad), k
+    ro2 = {"y": ro["y"].clone(), "z": ro["z"]}
+    ro2["y"][0, 300, 1, 2] += 1.0          # slice 9: nothing downstream re-rounds
+    o2, _ = run(ro2)
+    dy = (o2["_dbg"]["y_hat"] - d["y_hat"]).detach()
+    assert abs(dy[0, 300, 1, 2].item() - 1.0) < 0.6 and int((dy.abs() > 1e-3).sum()) <= 32 * 16
