@@ -15,6 +15,10 @@ for f in conv_igemm conv_wgrad pointwise entropy winattn; do
   fi
   objs="$objs build/$f.o"
 done
+if [ ! -f build/rans.o ] || [ csrc/rans.cpp -nt build/rans.o ] || [ ../include/icm_hip.h -nt build/rans.o ]; then
+  g++ -O2 -fPIC -std=c++17 -Wall -c csrc/rans.cpp -o build/rans.o || { echo "compile failed"; exit 1; }
+fi
+objs="$objs build/rans.o"
 for p in $pids; do wait $p || { echo "compile failed"; exit 1; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o lib/libicm_hip.so $objs
 echo "built lib/libicm_hip.so"

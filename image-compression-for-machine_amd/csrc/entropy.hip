@@ -350,6 +350,100 @@ __global__ void gc_bwd_kernel(const GcBwdDesc d) {
   }
 }
 
+// ------------------------------------------------------------------------------ codec tables / symbols (update, compress)
+// EntropyBottleneck.update() (entropy_models.py:354-393): per channel, minima = clamp(ceil(med - q0), 0),
+// maxima = clamp(ceil(q2 - med), 0) (ints); then the pmf of the integer grid med - minima + k, k < max_length.
+__global__ void eb_table_bounds_kernel(const float* __restrict__ quantiles, int C, int* __restrict__ minima,
+                                       int* __restrict__ maxima) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float q0 = quantiles[c * 3], med = quantiles[c * 3 + 1], q2 = quantiles[c * 3 + 2];
+  minima[c] = max((int)ceilf(med - q0), 0);
+  maxima[c] = max((int)ceilf(q2 - med), 0);
+}
+__global__ __launch_bounds__(256) void eb_pmf_table_kernel(const EbPtrs P, const int* __restrict__ minima, int C,
+                                                           int max_length, float* __restrict__ pmf,
+                                                           float* __restrict__ tail) {
+  __shared__ EbChan ch;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  eb_load_channel(P, c, &ch, tid);
+  __syncthreads();
+  const float start = ch.med - (float)minima[c];
+  for (int k = tid; k < max_length; k += 256) {
+    const float v = (float)k + start;
+    const float lo = eb_chain(ch, v - 0.5f, nullptr);
+    const float up = eb_chain(ch, v + 0.5f, nullptr);
+    const float sum = lo + up;
+    const float s = sum > 0.0f ? -1.0f : (sum < 0.0f ? 1.0f : 0.0f);
+    pmf[(long long)c * max_length + k] = fabsf(sigmoid_f(s * up) - sigmoid_f(s * lo));
+  }
+  if (tid == 0) {   // tail mass: sigmoid(lower of the first sample) + sigmoid(-upper of the last of max_length samples)
+    const float lo0 = eb_chain(ch, start - 0.5f, nullptr);
+    const float upL = eb_chain(ch, (float)(max_length - 1) + start + 0.5f, nullptr);
+    tail[c] = sigmoid_f(lo0) + sigmoid_f(-upL);
+  }
+}
+// GaussianConditional.update() (entropy_models.py:598-624): centers = ceil(scale * multiplier); pmf over |k - center|
+__global__ void gc_table_centers_kernel(const float* __restrict__ table, int ns, float multiplier,
+                                        int* __restrict__ centers) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ns) centers[i] = (int)ceilf(table[i] * multiplier);
+}
+__global__ void gc_pmf_table_kernel(const float* __restrict__ table, const int* __restrict__ centers, int ns,
+                                    int max_length, float* __restrict__ pmf, float* __restrict__ tail) {
+  const int i = blockIdx.y;
+  const float sc = table[i];
+  const int ctr = centers[i];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < max_length; k += gridDim.x * blockDim.x) {
+    const float v = (float)abs(k - ctr);
+    const float up = std_cdf((0.5f - v) / sc), lo = std_cdf((-0.5f - v) / sc);
+    pmf[(long long)i * max_length + k] = up - lo;
+    if (k == 0) tail[i] = 2.0f * lo;
+  }
+}
+// GaussianConditional.build_indexes (entropy_models.py:661-666): (ns - 1) - #{s in table[:-1] : max(scale, bound) <= s}
+__global__ void gc_build_indexes_kernel(const float* __restrict__ scale, long long sbs, const float* __restrict__ table,
+                                        int ns, float bound, int* __restrict__ idx, int N, int C, int HW) {
+  const long long per = (long long)C * HW, total = per * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / per, r = i - n * per;
+    const float s = fmaxf(scale[n * sbs + r], bound);
+    int v = ns - 1;
+    for (int k = 0; k < ns - 1; ++k) v -= (s <= table[k]) ? 1 : 0;
+    idx[i] = v;
+  }
+}
+// EntropyModel.quantize (entropy_models.py:126-150): r = round(x - mean); "symbols" -> int32, "dequantize" -> r + mean.
+// mean address = means + n*m_bs + c*m_cs + p*m_ps (full tensors, or per-channel medians with m_bs = m_ps = 0).
+__global__ void quantize_kernel(const float* __restrict__ x, long long xbs, const float* __restrict__ means,
+                                long long m_bs, long long m_cs, long long m_ps, int* __restrict__ sym,
+                                float* __restrict__ deq, int N, int C, int HW) {
+  const long long per = (long long)C * HW, total = per * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / per, r = i - n * per;
+    const int c = (int)(r / HW), p = (int)(r - (long long)c * HW);
+    const float m = means ? means[n * m_bs + c * m_cs + p * m_ps] : 0.0f;
+    const float q = rintf(x[n * xbs + r] - m);
+    if (sym) sym[i] = (int)q;
+    if (deq) deq[i] = q + m;
+  }
+}
+// EntropyModel.dequantize (entropy_models.py:159-166): float(symbols) + mean
+__global__ void dequantize_kernel(const int* __restrict__ sym, const float* __restrict__ means, long long m_bs,
+                                  long long m_cs, long long m_ps, float* __restrict__ out, long long obs, int N, int C,
+                                  int HW) {
+  const long long per = (long long)C * HW, total = per * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / per, r = i - n * per;
+    const int c = (int)(r / HW), p = (int)(r - (long long)c * HW);
+    const float m = means ? means[n * m_bs + c * m_cs + p * m_ps] : 0.0f;
+    out[n * obs + r] = (float)sym[i] + m;
+  }
+}
+
 }  // namespace icm
 
 using namespace icm;
@@ -396,6 +490,66 @@ int icm_eb_aux_loss(const icm_eb_params* p, float* loss, float* dquantiles, int 
   if (!eb_ok(p) || !loss || !dquantiles || C <= 0) return ICM_ERR_ARG;
   hipLaunchKernelGGL(eb_aux_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                      to_ptrs(p), loss, dquantiles, C, target);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+static inline int ew_blocks(long long total) {
+  return (int)std::max<long long>(1, std::min<long long>((total + 255) / 256, 2048));
+}
+
+int icm_eb_table_bounds(const float* quantiles, int C, int32_t* minima, int32_t* maxima, void* stream) {
+  if (!quantiles || !minima || !maxima || C <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(eb_table_bounds_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, quantiles, C,
+                     minima, maxima);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_eb_pmf_table(const icm_eb_params* p, const int32_t* minima, int C, int max_length, float* pmf, float* tail_mass,
+                     void* stream) {
+  if (!eb_ok(p) || !minima || !pmf || !tail_mass || C <= 0 || max_length <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(eb_pmf_table_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, to_ptrs(p), minima, C, max_length,
+                     pmf, tail_mass);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gc_table_centers(const float* scale_table, int ns, float multiplier, int32_t* centers, void* stream) {
+  if (!scale_table || !centers || ns <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gc_table_centers_kernel, dim3((ns + 255) / 256), dim3(256), 0, (hipStream_t)stream, scale_table, ns,
+                     multiplier, centers);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gc_pmf_table(const float* scale_table, const int32_t* centers, int ns, int max_length, float* pmf,
+                     float* tail_mass, void* stream) {
+  if (!scale_table || !centers || !pmf || !tail_mass || ns <= 0 || max_length <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gc_pmf_table_kernel, dim3((max_length + 255) / 256, ns), dim3(256), 0, (hipStream_t)stream,
+                     scale_table, centers, ns, max_length, pmf, tail_mass);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gc_build_indexes(const float* scale, int64_t scale_bs, const float* scale_table, int ns, float scale_bound,
+                         int32_t* indexes, int N, int C, int HW, void* stream) {
+  if (!scale || !scale_table || !indexes || ns <= 0 || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(gc_build_indexes_kernel, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream,
+                     scale, (long long)scale_bs, scale_table, ns, scale_bound, indexes, N, C, HW);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_quantize(const float* x, int64_t x_bs, const float* means, int64_t m_bs, int64_t m_cs, int64_t m_ps,
+                 int32_t* symbols, float* dequantized, int N, int C, int HW, void* stream) {
+  if (!x || (!symbols && !dequantized) || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(quantize_kernel, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)x_bs, means, (long long)m_bs, (long long)m_cs, (long long)m_ps, symbols, dequantized, N,
+                     C, HW);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_dequantize(const int32_t* symbols, const float* means, int64_t m_bs, int64_t m_cs, int64_t m_ps, float* out,
+                   int64_t out_bs, int N, int C, int HW, void* stream) {
+  if (!symbols || !out || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(dequantize_kernel, dim3(ew_blocks((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream,
+                     symbols, means, (long long)m_bs, (long long)m_cs, (long long)m_ps, out, (long long)out_bs, N, C, HW);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -495,6 +495,22 @@ __global__ void col2im_kernel(const float* __restrict__ cols, const float* __res
 __global__ void fill_kernel(float* p, long long n, float v) {
   GRID_STRIDE(i, n) p[i] = v;
 }
+__global__ void clamp_kernel(float* p, long long n, float lo, float hi) {
+  GRID_STRIDE(i, n) p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+// F.pad(x, (left, right, top, bottom), value) with negative pads = crop: dst[n,c,y,x] = src[n,c,y-top,x-left] or value
+__global__ void pad2d_kernel(const float* __restrict__ src, int N, int C, int H, int W, float* __restrict__ dst, int OH,
+                             int OW, int top, int left, float value) {
+  const long long total = (long long)N * C * OH * OW;
+  GRID_STRIDE(i, total) {
+    const int x = (int)(i % OW);
+    long long q = i / OW;
+    const int y = (int)(q % OH);
+    const long long nc = q / OH;
+    const int sy = y - top, sx = x - left;
+    dst[i] = ((unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) ? src[(nc * H + sy) * W + sx] : value;
+  }
+}
 
 // ---------------------------------------------------------------- R-D loss
 // stage 1: per-workgroup partial sums of (squared error, log lik_y, log lik_z) into ws[3][nblk];
@@ -783,6 +799,20 @@ int icm_col2im(const float* cols, const float* bias, float* out, int N, int C, i
 int icm_fill(float* p, int64_t n, float v, void* stream) {
   if (!p || n <= 0) return ICM_ERR_ARG;
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, (long long)n, v);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_clamp(float* p, int64_t n, float lo, float hi, void* stream) {
+  if (!p || n <= 0 || !(lo <= hi)) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, (long long)n, lo, hi);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, int OW, int top, int left, float value,
+              void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(pad2d_kernel, dim3(grid_for((long long)N * C * OH * OW)), dim3(256), 0, ST, src, N, C, H, W, dst, OH,
+                     OW, top, left, value);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

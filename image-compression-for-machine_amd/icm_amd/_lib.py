@@ -72,6 +72,10 @@ SYMBOLS = [
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_wgrad_cfg",
+    "icm_pmf_to_quantized_cdf", "icm_rans_encode_with_indexes", "icm_rans_decode_with_indexes",
+    "icm_rans_decoder_create", "icm_rans_decoder_decode", "icm_rans_decoder_destroy",
+    "icm_eb_table_bounds", "icm_eb_pmf_table", "icm_gc_table_centers", "icm_gc_pmf_table", "icm_gc_build_indexes",
+    "icm_quantize", "icm_dequantize", "icm_clamp", "icm_pad2d",
 ]
 REDUCE_WS_FLOATS = 8192   # ICM_REDUCE_WS_FLOATS
 
@@ -139,6 +143,26 @@ def lib():
         L.icm_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
         L.icm_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp, f32, f32, vp]
         L.icm_fill.argtypes = [vp, i64, f32, vp]
+        # entropy coding (host) + its device-side table / symbol kernels
+        i32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+        L.icm_pmf_to_quantized_cdf.argtypes = [C.POINTER(C.c_float), i32, i32, i32p]
+        L.icm_rans_encode_with_indexes.argtypes = [i32p, i32p, i64, i32p, i32, i32p, i32p, i32, vp, i64]
+        L.icm_rans_encode_with_indexes.restype = i64
+        L.icm_rans_decode_with_indexes.argtypes = [vp, i64, i32p, i64, i32p, i32, i32p, i32p, i32, i32p]
+        L.icm_rans_decoder_create.argtypes = [vp, i64]
+        L.icm_rans_decoder_create.restype = vp
+        L.icm_rans_decoder_decode.argtypes = [vp, i32p, i64, i32p, i32, i32p, i32p, i32, i32p]
+        L.icm_rans_decoder_destroy.argtypes = [vp]
+        L.icm_rans_decoder_destroy.restype = None
+        L.icm_eb_table_bounds.argtypes = [vp, i32, vp, vp, vp]
+        L.icm_eb_pmf_table.argtypes = [C.POINTER(EbParams), vp, i32, i32, vp, vp, vp]
+        L.icm_gc_table_centers.argtypes = [vp, i32, f32, vp, vp]
+        L.icm_gc_pmf_table.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.icm_gc_build_indexes.argtypes = [vp, i64, vp, i32, f32, vp, i32, i32, i32, vp]
+        L.icm_quantize.argtypes = [vp, i64, vp, i64, i64, i64, vp, vp, i32, i32, i32, vp]
+        L.icm_dequantize.argtypes = [vp, vp, i64, i64, i64, vp, i64, i32, i32, i32, vp]
+        L.icm_clamp.argtypes = [vp, i64, f32, f32, vp]
+        L.icm_pad2d.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, f32, vp]
         _lib = L
     return _lib
 

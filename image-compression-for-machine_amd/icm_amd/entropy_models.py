@@ -1,6 +1,8 @@
-"""compressai/entropy_models mirror: the *likelihood* halves of EntropyBottleneck and GaussianConditional
-(entropy_models.py:293-489, 525-659) on the fused HIP kernels.  update()/compress()/decompress() (rANS,
-CPU, inference-time: SURVEY.md 8 f2) are outside this round's scope and raise NotImplementedError."""
+"""compressai/entropy_models mirror: EntropyModel / EntropyBottleneck / GaussianConditional
+(entropy_models.py:66-666).  Likelihoods run on the fused HIP kernels; ``update()`` builds the quantised CDF tables
+from device-computed pmfs (``icm_eb_pmf_table`` / ``icm_gc_pmf_table`` + host ``icm_pmf_to_quantized_cdf``);
+``compress()`` / ``decompress()`` quantise on the device (``icm_quantize`` / ``icm_gc_build_indexes`` /
+``icm_dequantize``) and code the symbols with the host rANS coder (``icm_amd.ans``), as the reference does."""
 from __future__ import annotations
 
 import ctypes as C
@@ -46,15 +48,164 @@ class EntropyModel(nn.Module):
             return self._injected_noise.to(x.device, torch.float32).contiguous()
         return torch.rand(x.shape, dtype=torch.float32, device=x.device) - 0.5  # RNG plumbing (entropy_models.py:131-135)
 
+    # ---- quantisation (entropy_models.py:126-170)
+    @staticmethod
+    def _mean_strides(x, means):
+        """(tensor, m_bs, m_cs, m_ps) addressing ``means`` for every element of x [N,C,*]: full-size means, or means that
+        broadcast over the spatial dims / batch (per-channel medians: entropy_models.py:500-504)"""
+        if means is None:
+            return None, 0, 0, 0
+        N, Cc = x.shape[0], x.shape[1]
+        HW = x[0, 0].numel()
+        m = means.to(torch.float32)
+        if m.shape == x.shape:
+            m = m.contiguous()
+            return m, Cc * HW, HW, 1
+        if m.dim() == x.dim() and m.shape[1] == Cc and all(d == 1 for d in m.shape[2:]) and m.shape[0] in (1, N):
+            m = m.reshape(m.shape[0], Cc).contiguous()
+            return m, (Cc if m.shape[0] == N and N > 1 else 0), 1, 0
+        m = m.expand(x.shape).contiguous()
+        return m, Cc * HW, HW, 1
+
     def quantize(self, inputs, mode, means=None):
         if mode not in ("noise", "dequantize", "symbols"):
             raise ValueError(f'Invalid quantization mode: "{mode}"')
-        raise NotImplementedError("standalone quantize(): fused into the likelihood kernels on this path")
+        x = inputs.to(torch.float32).contiguous()
+        if mode == "noise":
+            out = x.clone()
+            noise = self._noise_like(x)
+            check(L.lib().icm_add_grad(ptr(noise), 0, ptr(out), out.numel(), 1, L.stream()), "add noise")
+            return out
+        if x.dim() < 2:
+            x = x.reshape(1, -1)
+            means = None if means is None else means.reshape(1, -1)
+        N, Cc = x.shape[0], x.shape[1]
+        HW = max(1, x[0, 0].numel())
+        m, mbs, mcs, mps = self._mean_strides(x, means)
+        sym = torch.empty(x.shape, dtype=torch.int32, device=x.device) if mode == "symbols" else None
+        deq = torch.empty_like(x) if mode == "dequantize" else None
+        check(L.lib().icm_quantize(ptr(x), Cc * HW, ptr(m), mbs, mcs, mps, ptr_any(sym), ptr(deq), N, Cc, HW, L.stream()),
+              "quantize")
+        return (sym if mode == "symbols" else deq).reshape(inputs.shape)
+
+    def _quantize(self, inputs, mode, means=None):
+        import warnings
+        warnings.warn("_quantize is deprecated. Use quantize instead.")
+        return self.quantize(inputs, mode, means)
+
+    @staticmethod
+    def dequantize(inputs, means=None):
+        """float(symbols) + means (entropy_models.py:159-166)"""
+        sym = inputs.to(torch.int32).contiguous()
+        if sym.dim() < 2:
+            out = sym.float()
+            return out + means if means is not None else out
+        N, Cc = sym.shape[0], sym.shape[1]
+        HW = max(1, sym[0, 0].numel())
+        m, mbs, mcs, mps = EntropyModel._mean_strides(sym, means)
+        out = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
+        check(L.lib().icm_dequantize(ptr_any(sym), ptr(m), mbs, mcs, mps, ptr(out), Cc * HW, N, Cc, HW, L.stream()),
+              "dequantize")
+        return out
+
+    @classmethod
+    def _dequantize(cls, inputs, means=None):
+        import warnings
+        warnings.warn("_dequantize. Use dequantize instead.")
+        return cls.dequantize(inputs, means)
+
+    # ---- CDF tables (entropy_models.py:172-199)
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        """quantised CDF rows from per-row pmfs (host: ``icm_pmf_to_quantized_cdf``), zero-padded to max_length + 2"""
+        from .ans import pmf_to_quantized_cdf
+        pm = pmf.detach().cpu().float().numpy()
+        tm = tail_mass.detach().cpu().float().numpy().reshape(len(pm), -1)
+        pl = [int(v) for v in pmf_length.detach().cpu().reshape(-1).tolist()]
+        cdf = torch.zeros((len(pl), int(max_length) + 2), dtype=torch.int32)
+        for i, n in enumerate(pl):
+            row = pmf_to_quantized_cdf(np.concatenate((pm[i, :n], tm[i, :1])), self.entropy_coder_precision)
+            cdf[i, :len(row)] = torch.tensor(row, dtype=torch.int32)
+        return cdf.to(pmf.device)
+
+    def _check_cdf_size(self):
+        if self._quantized_cdf.numel() == 0:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        if len(self._quantized_cdf.size()) != 2:
+            raise ValueError(f"Invalid CDF size {self._quantized_cdf.size()}")
+
+    def _check_offsets_size(self):
+        if self._offset.numel() == 0:
+            raise ValueError("Uninitialized offsets. Run update() first")
+        if len(self._offset.size()) != 1:
+            raise ValueError(f"Invalid offsets size {self._offset.size()}")
+
+    def _check_cdf_length(self):
+        if self._cdf_length.numel() == 0:
+            raise ValueError("Uninitialized CDF lengths. Run update() first")
+        if len(self._cdf_length.size()) != 1:
+            raise ValueError(f"Invalid offsets size {self._cdf_length.size()}")
+
+    def _tables(self):
+        """host copies of the coder tables, cached until the buffers change"""
+        from .ans import _Tables
+        key = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, tuple(self._quantized_cdf.shape))
+        if getattr(self, "_tab_key", None) != key:
+            self._tab = _Tables(self._quantized_cdf.detach().cpu().numpy(), self._cdf_length.detach().cpu().numpy(),
+                                self._offset.detach().cpu().numpy())
+            self._tab_key = key
+        return self._tab
+
+    # ---- coding (entropy_models.py:200-290)
+    def compress(self, inputs, indexes, means=None, flag=1):
+        symbols = self.quantize(inputs, "symbols", means)
+        if len(inputs.size()) < 2:
+            raise ValueError("Invalid `inputs` size. Expected a tensor with at least 2 dimensions.")
+        if inputs.size() != indexes.size():
+            raise ValueError("`inputs` and `indexes` should have the same size.")
+        self._check_cdf_size()
+        self._check_cdf_length()
+        self._check_offsets_size()
+        from .ans import _encode
+        t = self._tables()
+        sym = symbols.detach().cpu().numpy().astype(np.int32)
+        idx = indexes.detach().cpu().numpy().astype(np.int32)
+        return [_encode(np.ascontiguousarray(sym[i].reshape(-1)), np.ascontiguousarray(idx[i].reshape(-1)), t)
+                for i in range(sym.shape[0])]
+
+    def decompress(self, strings, indexes, means=None, flag=1):
+        if not isinstance(strings, (tuple, list)):
+            raise ValueError("Invalid `strings` parameter type.")
+        if not len(strings) == indexes.size(0):
+            raise ValueError("Invalid strings or indexes parameters")
+        if len(indexes.size()) < 2:
+            raise ValueError("Invalid `indexes` size. Expected a tensor with at least 2 dimensions.")
+        self._check_cdf_size()
+        self._check_cdf_length()
+        self._check_offsets_size()
+        if means is not None:
+            if means.size()[:2] != indexes.size()[:2]:
+                raise ValueError("Invalid means or indexes parameters")
+            if means.size() != indexes.size():
+                for i in range(2, len(indexes.size())):
+                    if means.size(i) != 1:
+                        raise ValueError("Invalid means parameters")
+        from .ans import RansDecoder
+        t = self._tables()
+        idx = indexes.detach().cpu().numpy().astype(np.int32)
+        out = np.empty(idx.shape, dtype=np.int32)
+        dec = RansDecoder()
+        for i, sbytes in enumerate(strings):
+            dec.set_stream(sbytes)
+            out[i] = dec.decode_stream_np(np.ascontiguousarray(idx[i].reshape(-1)), t).reshape(idx[i].shape)
+        sym = torch.from_numpy(out).to(self._quantized_cdf.device)
+        return self.dequantize(sym, means)
 
     def update(self, *a, **k):
-        raise NotImplementedError("CDF tables / rANS coding are not part of the training hot path (SURVEY 8 f2)")
+        raise NotImplementedError()
 
-    compress = decompress = update
+
+def ptr_any(t):
+    return 0 if t is None else t.data_ptr()
 
 
 class EntropyBottleneck(EntropyModel):
@@ -109,6 +260,56 @@ class EntropyBottleneck(EntropyModel):
         """aux loss (entropy_models.py:395-398): gradient flows to ``quantiles`` only."""
         return _EbAux.apply(self, self.quantiles)
 
+    def update(self, force: bool = False) -> bool:
+        """entropy_models.py:354-393: per-channel offsets and quantised CDFs of the learned density"""
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.quantiles.device
+        Cc = self.channels
+        st = L.stream()
+        q = self.quantiles.detach().contiguous()
+        minima = torch.empty(Cc, dtype=torch.int32, device=dev)
+        maxima = torch.empty(Cc, dtype=torch.int32, device=dev)
+        check(L.lib().icm_eb_table_bounds(ptr(q), Cc, minima.data_ptr(), maxima.data_ptr(), st), "eb_table_bounds")
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max().item())
+        P = {"e." + k: p.detach().contiguous() for k, p in self.named_parameters()}
+        prm = E._eb_params(P, "e")
+        pmf = torch.empty((Cc, max_length), dtype=torch.float32, device=dev)
+        tail = torch.empty(Cc, dtype=torch.float32, device=dev)
+        check(L.lib().icm_eb_pmf_table(C.byref(prm), minima.data_ptr(), Cc, max_length, ptr(pmf), ptr(tail), st),
+              "eb_pmf_table")
+        self._offset = -minima
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail.reshape(Cc, 1), pmf_length, max_length)
+        self._cdf_length = pmf_length + 2
+        return True
+
+    @staticmethod
+    def _build_indexes(size):
+        """channel index of every element (entropy_models.py:491-502)"""
+        N, Cc = size[0], size[1]
+        view = [1] * len(size)
+        view[1] = -1
+        return torch.arange(Cc, dtype=torch.int32).view(*view).repeat(N, 1, *size[2:])
+
+    @staticmethod
+    def _extend_ndims(tensor, n):
+        return tensor.reshape(-1, *([1] * n)) if n > 0 else tensor.reshape(-1)
+
+    def compress(self, x):
+        indexes = self._build_indexes(x.size())
+        spatial_dims = len(x.size()) - 2
+        medians = self._extend_ndims(self._get_medians().detach(), spatial_dims)
+        medians = medians.expand(x.size(0), *([-1] * (spatial_dims + 1)))
+        return super().compress(x, indexes, medians, 0)
+
+    def decompress(self, strings, size):
+        output_size = (len(strings), self._quantized_cdf.size(0), *size)
+        indexes = self._build_indexes(output_size)
+        medians = self._extend_ndims(self._get_medians().detach(), len(size))
+        medians = medians.expand(len(strings), *([-1] * (len(size) + 1)))
+        return super().decompress(strings, indexes, medians, 0)
+
 
 class _EbAux(torch.autograd.Function):
     @staticmethod
@@ -149,6 +350,68 @@ class GaussianConditional(EntropyModel):
         self.register_buffer("scale_table", torch.Tensor(tuple(float(s) for s in scale_table)) if scale_table
                              else torch.Tensor())
         self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]) if scale_bound is not None else None)
+
+    @staticmethod
+    def _prepare_scale_table(scale_table):
+        return torch.Tensor(tuple(float(s) for s in scale_table))
+
+    @staticmethod
+    def _standardized_quantile(quantile):
+        import scipy.stats
+        return scipy.stats.norm.ppf(quantile)
+
+    def update_scale_table(self, scale_table, force=False):
+        """entropy_models.py:585-596"""
+        if self._offset.numel() > 0 and not force:
+            return False
+        device = self.scale_table.device
+        self.scale_table = self._prepare_scale_table(scale_table).to(device)
+        self.update()
+        return True
+
+    def update(self):
+        """entropy_models.py:598-624: one quantised Gaussian CDF per entry of the scale table"""
+        dev = self.scale_table.device
+        ns = int(self.scale_table.numel())
+        if ns == 0:
+            raise ValueError("empty scale_table: call update_scale_table() first")
+        st = L.stream()
+        multiplier = float(-self._standardized_quantile(self.tail_mass / 2))
+        table = self.scale_table.detach().to(torch.float32).contiguous()
+        centers = torch.empty(ns, dtype=torch.int32, device=dev)
+        check(L.lib().icm_gc_table_centers(ptr(table), ns, multiplier, centers.data_ptr(), st), "gc_table_centers")
+        pmf_length = 2 * centers + 1
+        max_length = int(pmf_length.max().item())
+        pmf = torch.empty((ns, max_length), dtype=torch.float32, device=dev)
+        tail = torch.empty(ns, dtype=torch.float32, device=dev)
+        check(L.lib().icm_gc_pmf_table(ptr(table), centers.data_ptr(), ns, max_length, ptr(pmf), ptr(tail), st),
+              "gc_pmf_table")
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail.reshape(ns, 1), pmf_length, max_length)
+        self._offset = -centers
+        self._cdf_length = pmf_length + 2
+
+    def build_indexes(self, scales):
+        """index of the first table entry >= max(scale, bound) (entropy_models.py:661-666)"""
+        sc = scales.to(torch.float32).contiguous()
+        N, Cc = sc.shape[0], sc.shape[1]
+        HW = max(1, sc[0, 0].numel())
+        idx = torch.empty(sc.shape, dtype=torch.int32, device=sc.device)
+        table = self.scale_table.detach().to(sc.device, torch.float32).contiguous()
+        check(L.lib().icm_gc_build_indexes(ptr(sc), Cc * HW, ptr(table), int(table.numel()), self._scale_bound,
+                                           idx.data_ptr(), N, Cc, HW, L.stream()), "gc_build_indexes")
+        return idx
+
+    def _likelihood(self, inputs, scales, means=None):
+        """entropy_models.py:626-643 (no likelihood bound, no quantisation): the fused kernel in eval mode on integer-
+        offset inputs reproduces it; exposed for API parity"""
+        if means is None:
+            means = torch.zeros_like(inputs)
+        lik = E.new(inputs)
+        tape = E.Tape(need_grad=False)
+        # the kernel quantises round(x - mu) + mu: callers of _likelihood pass already-quantised inputs
+        E.gc_likelihood_ste(tape, inputs.contiguous(), means.contiguous(), scales.contiguous(), None, lik, None, None,
+                            self._scale_bound, 0.0)
+        return lik
 
     def forward(self, inputs, scales, means=None, training: Optional[bool] = None):
         if training is None:

@@ -41,7 +41,49 @@ class CompressionModel(nn.Module):
         raise NotImplementedError()
 
     def update(self, force=False):
-        raise NotImplementedError("CDF update / entropy coding is outside the training hot path (SURVEY 8 f2)")
+        """models/base.py:43-60: refresh the CDF tables of every EntropyBottleneck child"""
+        updated = False
+        for m in self.children():
+            if not isinstance(m, EntropyBottleneck):
+                continue
+            updated |= m.update(force=force)
+        return updated
+
+    # ---- shared by the cnn and stf models: entropy coding around the slice loop (cnn.py:133-139,210-332)
+    def _update_tables(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= CompressionModel.update(self, force=force)
+        return updated
+
+    def _params(self):
+        names, params = _named(self)
+        return dict(zip(names, [p.detach() for p in params]))
+
+    def _compress_latent(self, tape, P, y):
+        """cnn.py:214-266 from ``y`` on: {"strings": [[y_string], z_strings], "shape": z spatial size}"""
+        from .ans import _encode
+        codec = {"gc": self.gaussian_conditional, "symbols": {}, "indexes": {}}
+        keep = {}
+        hyper_slices(tape, P, y, None, None, self.num_slices, self.max_support_slices, keep=keep, codec=codec)
+        z = keep["z"]
+        z_strings = self.entropy_bottleneck.compress(z)
+        sym = torch.cat([codec["symbols"][i].reshape(-1) for i in range(self.num_slices)]).cpu().numpy()
+        idx = torch.cat([codec["indexes"][i].reshape(-1) for i in range(self.num_slices)]).cpu().numpy()
+        self.gaussian_conditional._check_cdf_size()
+        self.gaussian_conditional._check_cdf_length()
+        self.gaussian_conditional._check_offsets_size()
+        y_string = _encode(sym, idx, self.gaussian_conditional._tables())
+        return {"strings": [[y_string], z_strings], "shape": z.size()[-2:]}
+
+    def _decompress_latent(self, tape, P, strings, shape, M):
+        """cnn.py:289-328: y_hat from the two streams"""
+        if not isinstance(strings, (list, tuple)) or len(strings) != 2:
+            raise ValueError("strings must be [y_strings, z_strings]")
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        return decode_slices(tape, P, z_hat, strings[0][0], self.gaussian_conditional, self.num_slices,
+                             self.max_support_slices, M)
 
     def load_state_dict(self, state_dict, strict: bool = False):
         # models/base.py:62-70: resize the CDF buffers to whatever the checkpoint holds, then strict=False
@@ -113,14 +155,26 @@ def _copy_op(tape, src, dst):
 
 def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, num_slices: int,
                  max_support: int, keep: Optional[dict] = None, bucket_marks: Optional[dict] = None,
-                 batch_tail: bool = True):
+                 batch_tail: bool = True, codec: Optional[dict] = None, decode: Optional[dict] = None):
     """Hyperprior + channel-conditional slice loop shared by the cnn and stf models
     (cnn.py:144-183 == stf.py:596-637) -> (y_hat, y_likelihoods, z_likelihoods).  torch.cat / chunk become
-    channel-slice views of persistent support buffers."""
-    dev = y.device
-    N = y.shape[0]
+    channel-slice views of persistent support buffers.
+    codec (compress(), cnn.py:246-252): {"gc": GaussianConditional, "symbols": {}, "indexes": {}} -- the int32 symbols
+    round(y - mu) and CDF indexes of every slice are recorded (device tensors, keyed by slice).
+    decode (decompress(), cnn.py:289-326): {"z_hat", "M", "slice": callable(i, mu, sc, yh_pre)} -- y is None; the
+    SAME launch sequence runs (identical kernels on identical inputs give the bit-identical mu / scale the encoder saw,
+    which the CDF indexes depend on), but each slice's y_hat_pre comes from the entropy decoder instead of from y."""
+    if decode is not None:
+        z_hat = decode["z_hat"].contiguous()
+        dev, N, M = z_hat.device, z_hat.shape[0], decode["M"]
+        h, w = z_hat.shape[2] * 4, z_hat.shape[3] * 4
+        if tape.need_grad:
+            raise ValueError("decode mode is inference only")
+    else:
+        dev = y.device
+        N = y.shape[0]
+        M, h, w = y.shape[1], y.shape[2], y.shape[3]
     need = tape.need_grad
-    M, h, w = y.shape[1], y.shape[2], y.shape[3]
     if M % num_slices != 0:
         raise ValueError("latent channels must divide into num_slices")
     sc_ = M // num_slices
@@ -132,9 +186,11 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
     if bucket_marks is not None:
         bucket_marks[2] = len(tape.bw)   # backward reaching here => hyper-path gradients are complete
     # ---- h_a + entropy bottleneck (cnn.py:144-152)
-    z = _chain(tape, P, "h_a", VT(y), strides=(1, 1, 2, 1, 2))
-    _, z_lik = E.eb_likelihood(tape, z, P, "entropy_bottleneck", noise_z)
-    z_hat = E.ste_round_medians(tape, z, P["entropy_bottleneck.quantiles"])
+    z = z_lik = None
+    if decode is None:
+        z = _chain(tape, P, "h_a", VT(y), strides=(1, 1, 2, 1, 2))
+        _, z_lik = E.eb_likelihood(tape, z, P, "entropy_bottleneck", noise_z)
+        z_hat = E.ste_round_medians(tape, z, P["entropy_bottleneck.quantiles"])
     # ---- hyper synthesis straight into the support buffers (cnn.py:154-155,163,167)
     nsup = sc_ * max_support
     MS = E.new((N, M + nsup, h, w), dev)
@@ -152,7 +208,7 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
         raise ValueError("hyper-synthesis output does not match the latent size (input must be a multiple of 64)")
     _h_s_pair(tape, P, "h_scale_s", "h_mean_s", z_hat, SS[:, :M], MS[:, :M])
     Y_hat = E.new((N, M, h, w), dev)
-    Y_lik = E.new((N, M, h, w), dev)
+    Y_lik = E.new((N, M, h, w), dev) if decode is None else None
     if need:
         dYh = E.zeros(Y_hat.shape, dev)
         tape.bind_grad(Y_hat, dYh, True)
@@ -179,7 +235,13 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
             tape.bind_grad(LS[:, :M + sc_ * k], dLS[:, :M + sc_ * k], True)
             tape.bind_grad(yh_pre, dLS[:, M + sc_ * k:], True)
         _copy_op(tape, ms, LS[:, :M + sc_ * k])
-        E.gc_likelihood_ste(tape, y[:, ch], mu, sc, None if noise_y is None else noise_y[:, ch], Y_lik[:, ch], yh_pre)
+        if decode is not None:
+            decode["slice"](i, mu, sc, yh_pre)
+        else:
+            E.gc_likelihood_ste(tape, y[:, ch], mu, sc, None if noise_y is None else noise_y[:, ch], Y_lik[:, ch],
+                                yh_pre)
+        if codec is not None:
+            _record_symbols(codec, i, y[:, ch], mu, sc)
         _chain(tape, P, f"lrp_transforms.{i}", VT(LS), out=Y_hat[:, ch], lrp_aux=yh_pre)
         if i < max_support:
             sl = slice(M + sc_ * i, M + sc_ * (i + 1))
@@ -213,8 +275,13 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
                 tape.bind_grad(LS[:, :M + sc_ * k], dLS[:, :M + sc_ * k], True)
                 tape.bind_grad(yh_pre, dLS[:, M + sc_ * k:], True)
             _copy_op(tape, ms, LS[:, :M + sc_ * k])
-            E.gc_likelihood_ste(tape, y[:, ch], mu_t[j], sc_t[j], None if noise_y is None else noise_y[:, ch],
-                                Y_lik[:, ch], yh_pre)
+            if decode is not None:
+                decode["slice"](i, mu_t[j], sc_t[j], yh_pre)
+            else:
+                E.gc_likelihood_ste(tape, y[:, ch], mu_t[j], sc_t[j], None if noise_y is None else noise_y[:, ch],
+                                    Y_lik[:, ch], yh_pre)
+            if codec is not None:
+                _record_symbols(codec, i, y[:, ch], mu_t[j], sc_t[j])
             LSs.append(LS)
             pres.append(yh_pre)
         # lrp chains of all tail slices, LRP tail fused into the last grouped launch
@@ -237,6 +304,44 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
     return Y_hat, Y_lik, z_lik
 
 
+def _record_symbols(codec, i, y_slice, mu, sc):
+    """symbols = quantize(y_slice, "symbols", mu) and indexes = build_indexes(scale) of slice i (cnn.py:246-252)"""
+    N, Cc, h, w = y_slice.shape
+    sym = torch.empty((N, Cc, h, w), dtype=torch.int32, device=y_slice.device)
+    L.check(L.lib().icm_quantize(L.ptr(y_slice), L.bs(y_slice), L.ptr(mu), L.bs(mu), h * w, 1, sym.data_ptr(), 0, N, Cc,
+                                 h * w, L.stream()), "quantize")
+    codec["symbols"][i] = sym
+    codec["indexes"][i] = codec["gc"].build_indexes(sc)
+
+
+def decode_slices(tape: E.Tape, P, z_hat, y_string: bytes, gc, num_slices: int, max_support: int, M: int):
+    """Decoder side of the slice loop (cnn.py:296-326): hyper_slices in decode mode -- per slice the chains give
+    mu / scale -> CDF indexes -> the rANS decoder yields the symbols -> y_hat_pre = symbols + mu; the LRP correction
+    and the support bookkeeping are the forward's own.  Returns y_hat [N,M,h,w]."""
+    from .ans import RansDecoder
+    gc._check_cdf_size()
+    gc._check_cdf_length()
+    gc._check_offsets_size()
+    tabs = gc._tables()
+    dec = RansDecoder()
+    dec.set_stream(y_string)
+    state = {"next": 0}
+
+    def one(i, mu, sc, yh_pre):
+        if i != state["next"]:
+            raise RuntimeError("slices must be decoded in stream order")
+        state["next"] += 1
+        N, Cc, h, w = mu.shape
+        idx = gc.build_indexes(sc).cpu().numpy().reshape(-1)
+        sym = torch.from_numpy(dec.decode_stream_np(idx, tabs).reshape(N, Cc, h, w)).to(mu.device)
+        L.check(L.lib().icm_dequantize(sym.data_ptr(), L.ptr(mu), L.bs(mu), h * w, 1, L.ptr(yh_pre), L.bs(yh_pre), N, Cc,
+                                       h * w, tape.st), "dequantize")
+
+    Y_hat, _, _ = hyper_slices(tape, P, None, None, None, num_slices, max_support,
+                               decode={"z_hat": z_hat, "M": M, "slice": one})
+    return Y_hat
+
+
 def _split_lik(tape, Y_lik, num_slices):
     """runs FIRST in backward (registered last): hand the seeded d(y_likelihoods) to the per-slice consumers"""
     sc_ = Y_lik.shape[1] // num_slices
@@ -253,7 +358,16 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
                   num_slices: int = 10, max_support: int = 5, keep: Optional[dict] = None,
                   bucket_marks: Optional[dict] = None):
     """WACNN.forward (models/cnn.py:141-189) on the HIP engine -> (x_hat, y_likelihoods, z_likelihoods)."""
-    # ---- g_a (cnn.py:31-41)
+    y = wacnn_g_a(tape, P, x)
+    Y_hat, Y_lik, z_lik = hyper_slices(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks)
+    x_hat = wacnn_g_s(tape, P, Y_hat)
+    if tape.need_grad:
+        _split_lik(tape, Y_lik, num_slices)
+    return x_hat, Y_lik, z_lik
+
+
+def wacnn_g_a(tape: E.Tape, P, x):
+    """analysis transform g_a (cnn.py:31-41)"""
     t = E.conv2d_thin_in(tape, x, P["g_a.0.weight"], P["g_a.0.bias"], stride=2, pad=2)
     t = E.gdn(tape, t, P["g_a.1.beta"], P["g_a.1.gamma"], False)
     t = E.conv2d(tape, VT(t), P["g_a.2.weight"], P["g_a.2.bias"], stride=2, pad=2)
@@ -262,9 +376,11 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
     t = E.conv2d(tape, VT(t), P["g_a.5.weight"], P["g_a.5.bias"], stride=2, pad=2)
     t = E.gdn(tape, t, P["g_a.6.beta"], P["g_a.6.gamma"], False)
     t = E.conv2d(tape, VT(t), P["g_a.7.weight"], P["g_a.7.bias"], stride=2, pad=2)
-    y = E.attention_gate(tape, t, P, "g_a.8", 8, 4, 2)
-    Y_hat, Y_lik, z_lik = hyper_slices(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks)
-    # ---- g_s (cnn.py:42-52)
+    return E.attention_gate(tape, t, P, "g_a.8", 8, 4, 2)
+
+
+def wacnn_g_s(tape: E.Tape, P, Y_hat):
+    """synthesis transform g_s (cnn.py:42-52)"""
     t = E.attention_gate(tape, Y_hat, P, "g_s.0", 8, 4, 2)
     t = E.conv2d(tape, VT(t), P["g_s.1.weight"], P["g_s.1.bias"], stride=2, pad=2, transposed=True, output_padding=1)
     t = E.gdn(tape, t, P["g_s.2.beta"], P["g_s.2.gamma"], True)
@@ -273,10 +389,7 @@ def wacnn_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noi
     t = E.attention_gate(tape, t, P, "g_s.5", 8, 8, 4)
     t = E.conv2d(tape, VT(t), P["g_s.6.weight"], P["g_s.6.bias"], stride=2, pad=2, transposed=True, output_padding=1)
     t = E.gdn(tape, t, P["g_s.7.beta"], P["g_s.7.gamma"], True)
-    x_hat = E.convT2d_thin_out(tape, VT(t), P["g_s.8.weight"], P["g_s.8.bias"], stride=2, pad=2, output_padding=1)
-    if tape.need_grad:
-        _split_lik(tape, Y_lik, num_slices)
-    return x_hat, Y_lik, z_lik
+    return E.convT2d_thin_out(tape, VT(t), P["g_s.8.weight"], P["g_s.8.bias"], stride=2, pad=2, output_padding=1)
 
 
 # ------------------------------------------------------------------------------------------------ stf
@@ -320,26 +433,65 @@ def stf_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise
     """SymmetricalTransFormer.forward (models/stf.py:582-645) on the HIP engine.  Tokens stay NCHW end to end:
     [B, L, C] <-> [B, C, H, W] transposes of the reference vanish, Linear layers are 1x1 implicit GEMMs,
     LayerNorm normalises the channel axis per pixel.  drops: {"<layer>.blocks.<j>": [2,B] DropPath scales}."""
+    y = stf_analysis(tape, P, x, drops, window)
+    Y_hat, Y_lik, z_lik = hyper_slices(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks)
+    x_hat = stf_synthesis(tape, P, Y_hat, drops, window)
+    if tape.need_grad:
+        _split_lik(tape, Y_lik, num_slices)
+    return x_hat, Y_lik, z_lik
+
+
+def stf_analysis(tape: E.Tape, P, x, drops=None, window: int = 4):
+    """patch_embed + layers (stf.py:582-595)"""
     if x.shape[2] % 2 or x.shape[3] % 2:
-        raise ValueError("stf_forward: odd image sizes need PatchEmbed padding (inputs are multiples of 64)")
+        raise ValueError("stf: odd image sizes need PatchEmbed padding (pad the input to a multiple of 64)")
     # ---- patch_embed (stf.py:331-351): conv 2x2 s2 + LayerNorm
     t = E.conv2d_thin_in(tape, x, P["patch_embed.proj.weight"], P["patch_embed.proj.bias"], stride=2, pad=0)
     t = E.layernorm(tape, t, P["patch_embed.norm.weight"], P["patch_embed.norm.bias"])
     for i in range(4):
         t = _basic_layer(tape, P, f"layers.{i}", t, STF_DEPTHS[i], STF_HEADS[i], window, "merge" if i < 3 else None,
                          drops)
-    y = t
-    Y_hat, Y_lik, z_lik = hyper_slices(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks)
+    return t
+
+
+def stf_synthesis(tape: E.Tape, P, Y_hat, drops=None, window: int = 4):
+    """syn_layers + end_conv (stf.py:638-645)"""
     t = Y_hat
     for i in range(4):
         t = _basic_layer(tape, P, f"syn_layers.{i}", t, STF_DEPTHS[3 - i], STF_HEADS[3 - i], window,
                          "split" if i < 3 else None, drops)
     # ---- end_conv (stf.py:401-404): conv5x5 -> PixelShuffle(2) (fused store) -> conv3x3
     t = E.conv2d(tape, VT(t), P["end_conv.0.weight"], P["end_conv.0.bias"], pad=2, pixel_shuffle=2)
-    x_hat = E.conv2d(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
-    if tape.need_grad:
-        _split_lik(tape, Y_lik, num_slices)
-    return x_hat, Y_lik, z_lik
+    return E.conv2d(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
+
+
+def _pad_eval_input(x, training: bool):
+    """Inputs whose sides are not multiples of 64 (six stride-2 stages).  The reference pads feature maps inside its
+    Swin blocks (stf.py:158-163) and crops the slice-chain outputs (cnn.py:165,169), but its own evaluation entry
+    point zero-pads the IMAGE to a multiple of 64 first (utils/eval_model/__main__.py:162-175), after which none of
+    those branches is taken; this mirror does exactly that outer padding in eval mode and crops x_hat back
+    (likelihoods cover the padded image, as they do in the reference's eval loop).  Training crops are 256x256."""
+    if x.shape[2] % 64 == 0 and x.shape[3] % 64 == 0:
+        return x, None
+    if training or torch.is_grad_enabled() and x.requires_grad:
+        raise ValueError("training inputs must be multiples of 64 (the reference trains on 256x256 crops)")
+    from .utils import pad_to_multiple
+    return pad_to_multiple(x, 64)
+
+
+def _crop_eval_output(x_hat, pads):
+    if pads is None:
+        return x_hat
+    from .utils import crop
+    return crop(x_hat, pads)
+
+
+def _check_codec_input(x):
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError("expected [B,3,H,W]")
+    if x.shape[2] % 64 or x.shape[3] % 64:
+        raise ValueError("compress(): pad the image to a multiple of 64 first (icm_amd.utils.pad_to_multiple; the "
+                         "reference's eval loop does the same, utils/eval_model/__main__.py:102-117)")
 
 
 def _train_noise(injected, x, cz, cy):
@@ -408,6 +560,7 @@ class WACNN(CompressionModel):
         names, params = _named(self)
         training = self.training
         dev = x.device
+        x, pads = _pad_eval_input(x, training)
         nz = ny = None
         if training:
             nz, ny = _train_noise(self._noise, x, 192, 320)
@@ -417,13 +570,34 @@ class WACNN(CompressionModel):
             return wacnn_forward(tape, dict(zip(names, ps)), xin, nz, ny, ns, ms)
 
         x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
-        return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
+        return {"x_hat": _crop_eval_output(x_hat, pads), "likelihoods": {"y": y_lik, "z": z_lik}}
 
     @classmethod
     def from_state_dict(cls, state_dict):
         net = cls(192, 320)
         net.load_state_dict(state_dict)
         return net
+
+    def update(self, scale_table=None, force=False):
+        """cnn.py:133-138"""
+        return self._update_tables(scale_table, force)
+
+    @torch.no_grad()
+    def compress(self, x):
+        """cnn.py:210-266 -> {"strings": [[y_string], z_strings], "shape": z.shape[-2:]}"""
+        _check_codec_input(x)
+        P = self._params()
+        tape = E.Tape(need_grad=False)
+        return self._compress_latent(tape, P, wacnn_g_a(tape, P, x.contiguous()))
+
+    @torch.no_grad()
+    def decompress(self, strings, shape):
+        """cnn.py:289-332 -> {"x_hat"} clamped to [0, 1]"""
+        P = self._params()
+        tape = E.Tape(need_grad=False)
+        x_hat = wacnn_g_s(tape, P, self._decompress_latent(tape, P, strings, shape, 320))
+        L.check(L.lib().icm_clamp(L.ptr(x_hat), x_hat.numel(), 0.0, 1.0, tape.st), "clamp")
+        return {"x_hat": x_hat}
 
 
 # ------------------------------------------------------------------------------------------------ stf modules
@@ -639,6 +813,7 @@ class SymmetricalTransFormer(CompressionModel):
             raise ValueError("SymmetricalTransFormer.forward expects [B,3,H,W]")
         names, params = _named(self)
         dev = x.device
+        x, pads = _pad_eval_input(x, self.training)
         nz = ny = drops = None
         if self.training:
             nz, ny = _train_noise(self._noise, x, 192, 384)
@@ -650,10 +825,31 @@ class SymmetricalTransFormer(CompressionModel):
             return stf_forward(tape, dict(zip(names, ps)), xin, nz, ny, drops, ns, ms, ws)
 
         x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
-        return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
+        return {"x_hat": _crop_eval_output(x_hat, pads), "likelihoods": {"y": y_lik, "z": z_lik}}
 
     @classmethod
     def from_state_dict(cls, state_dict):
         net = cls()
         net.load_state_dict(state_dict)
         return net
+
+    def update(self, scale_table=None, force=False):
+        """stf.py: same table refresh as the cnn model (cnn.py:133-138)"""
+        return self._update_tables(scale_table, force)
+
+    @torch.no_grad()
+    def compress(self, x):
+        """stf.py compress(): analysis transform, then the shared latent coder"""
+        _check_codec_input(x)
+        P = self._params()
+        tape = E.Tape(need_grad=False)
+        return self._compress_latent(tape, P, stf_analysis(tape, P, x.contiguous(), None, self.window_size))
+
+    @torch.no_grad()
+    def decompress(self, strings, shape):
+        P = self._params()
+        tape = E.Tape(need_grad=False)
+        y_hat = self._decompress_latent(tape, P, strings, shape, 384)
+        x_hat = stf_synthesis(tape, P, y_hat, None, self.window_size)
+        L.check(L.lib().icm_clamp(L.ptr(x_hat), x_hat.numel(), 0.0, 1.0, tape.st), "clamp")
+        return {"x_hat": x_hat}

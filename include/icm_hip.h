@@ -234,6 +234,49 @@ int icm_gc_likelihood_ste_bwd(const float* y, int64_t y_bs, const float* mu, int
                               float* dscale, int64_t dsc_bs, int N, int C, int HW, float scale_bound,
                               float lik_bound, int accum_dy, void* stream);
 
+/* ---- entropy coding: CDF tables and the rANS stream -----------------------------------------
+ * Replaces the calls entropy_models.py:60-63,172-290 makes into the reference's binary-only extensions
+ * `compressai._CXX.pmf_to_quantized_cdf` and `compressai.ans.{RansEncoder,RansDecoder,BufferedRansEncoder}`
+ * (CompressAI 1.1.6dev0 cpp_exts, sources absent from the tree; state machine = third_party/ryg_rans/rans64.h).
+ * HOST functions: pointers are host memory, nothing touches the GPU.
+ *
+ * cdf[0..n]: quantised cumulative table of pmf[0..n-1] with cdf[n] = 2^precision and no zero-width symbol. */
+int icm_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf);
+/* cdfs: ncdf tables of cdf_stride int32 each (row i valid for cdf_sizes[i] entries, last bin = escape);
+ * symbol i is coded with table indexes[i] after subtracting offsets[indexes[i]].  Returns the stream length in bytes
+ * (a multiple of 4), -1 on bad arguments / capacity; out = NULL only measures. */
+int64_t icm_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n, const int32_t* cdfs,
+                                     int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int ncdf,
+                                     uint8_t* out, int64_t out_capacity);
+int icm_rans_decode_with_indexes(const uint8_t* stream, int64_t nbytes, const int32_t* indexes, int64_t n,
+                                 const int32_t* cdfs, int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                                 int ncdf, int32_t* out);
+/* RansDecoder.set_stream / decode_stream (cnn.py:300-318): one stream consumed by successive calls */
+void* icm_rans_decoder_create(const uint8_t* stream, int64_t nbytes);
+int icm_rans_decoder_decode(void* decoder, const int32_t* indexes, int64_t n, const int32_t* cdfs, int cdf_stride,
+                            const int32_t* cdf_sizes, const int32_t* offsets, int ncdf, int32_t* out);
+void icm_rans_decoder_destroy(void* decoder);
+
+/* device side of update() / compress() / decompress() (stream-ordered like every other kernel entry point) */
+/* EntropyBottleneck.update (entropy_models.py:354-393): minima / maxima [C] int32, then pmf [C][max_length] and
+ * tail_mass [C] on the integer grid median - minima + k */
+int icm_eb_table_bounds(const float* quantiles, int C, int32_t* minima, int32_t* maxima, void* stream);
+int icm_eb_pmf_table(const icm_eb_params* p, const int32_t* minima, int C, int max_length, float* pmf, float* tail_mass,
+                     void* stream);
+/* GaussianConditional.update (entropy_models.py:598-624): centers = ceil(scale_table * multiplier); pmf [ns][max_length] */
+int icm_gc_table_centers(const float* scale_table, int ns, float multiplier, int32_t* centers, void* stream);
+int icm_gc_pmf_table(const float* scale_table, const int32_t* centers, int ns, int max_length, float* pmf,
+                     float* tail_mass, void* stream);
+/* GaussianConditional.build_indexes (entropy_models.py:661-666) */
+int icm_gc_build_indexes(const float* scale, int64_t scale_bs, const float* scale_table, int ns, float scale_bound,
+                         int32_t* indexes, int N, int C, int HW, void* stream);
+/* EntropyModel.quantize "symbols" / "dequantize" (entropy_models.py:126-150) and dequantize (:159-166); the mean of
+ * element (n,c,p) is means[n*m_bs + c*m_cs + p*m_ps] (means NULL = 0): full tensors or per-channel medians */
+int icm_quantize(const float* x, int64_t x_bs, const float* means, int64_t m_bs, int64_t m_cs, int64_t m_ps,
+                 int32_t* symbols, float* dequantized, int N, int C, int HW, void* stream);
+int icm_dequantize(const int32_t* symbols, const float* means, int64_t m_bs, int64_t m_cs, int64_t m_ps, float* out,
+                   int64_t out_bs, int N, int C, int HW, void* stream);
+
 /* ---- R-D loss (train.py:53-61, train_czigzag.py:63,71) --------------------------------------
  * out[0]=bpp, out[1]=mse, out[2]=loss, out[3]=sum log(lik_y), out[4]=sum log(lik_z) (5 floats, overwritten);
  * ws: ICM_REDUCE_WS_FLOATS floats of scratch (per-workgroup partial sums, added in workgroup order). */
@@ -255,6 +298,12 @@ int icm_grad_sqnorm(const float* g, int64_t n, float* out, float* ws, void* stre
 int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream);
 int icm_fill(float* p, int64_t n, float v, void* stream);
+/* x_hat.clamp_(0, 1) of decompress() (cnn.py:330) */
+int icm_clamp(float* p, int64_t n, float lo, float hi, void* stream);
+/* F.pad(x, (left, ., top, .), value) / its negative-pad crop around the codec (utils/eval_model/__main__.py:102-117,
+ * 129-131): dst [N,C,OH,OW], dst[y][x] = src[y - top][x - left] inside the source, `value` outside */
+int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, int OW, int top, int left, float value,
+              void* stream);
 
 /* ---- test hooks (process-global; used by the parity tests and tools/tune_conv.py only) ----------------------
  * force the implicit-GEMM tile configuration (index into the kernel table, -1 = automatic) / the weight-gradient

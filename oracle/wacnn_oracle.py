@@ -231,6 +231,56 @@ def gaussian_likelihood(y: Tensor, scales: Tensor, means: Tensor, noise: Optiona
     return out, lik
 
 
+# --------------------------------------------------------------------------- CDF tables (update())
+def eb_update_tables(sd, p: str = "entropy_bottleneck"):
+    """EntropyBottleneck.update up to the pmf (entropy_models.py:354-390): returns (offset [C] int, pmf [C,L],
+    tail_mass [C,1], pmf_length [C] int, max_length).  The quantisation of each row to a CDF is the coder's
+    pmf_to_quantized_cdf (oracle/rans_oracle.py)."""
+    q = sd[p + ".quantiles"].detach()
+    medians = q[:, 0, 1]
+    minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+    maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+    pmf_start = medians - minima
+    pmf_length = maxima + minima + 1
+    max_length = int(pmf_length.max().item())
+    samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+    lower = eb_logits_cumulative(samples - 0.5, sd, p, True).detach()
+    upper = eb_logits_cumulative(samples + 0.5, sd, p, True).detach()
+    sign = -torch.sign(lower + upper)
+    pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+    tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+    return -minima, pmf, tail_mass, pmf_length, max_length
+
+
+def gc_update_tables(scale_table: Tensor, tail_mass: float = 1e-9):
+    """GaussianConditional.update up to the pmf (entropy_models.py:598-620): (offset, pmf, tail_mass, pmf_length, max_length)"""
+    import scipy.stats
+    multiplier = -scipy.stats.norm.ppf(tail_mass / 2)
+    pmf_center = torch.ceil(scale_table * multiplier).int()
+    pmf_length = 2 * pmf_center + 1
+    max_length = int(torch.max(pmf_length).item())
+    samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+    sc = scale_table.unsqueeze(1).float()
+    c = -(2 ** -0.5)
+    upper = 0.5 * torch.erfc(c * ((0.5 - samples) / sc))
+    lower = 0.5 * torch.erfc(c * ((-0.5 - samples) / sc))
+    return -pmf_center, upper - lower, 2 * lower[:, :1], pmf_length, max_length
+
+
+def gc_build_indexes(scales: Tensor, scale_table: Tensor) -> Tensor:
+    """GaussianConditional.build_indexes (entropy_models.py:661-666)"""
+    s = torch.max(scales, torch.tensor(SCALE_BOUND))
+    idx = torch.full(s.shape, len(scale_table) - 1, dtype=torch.int32)
+    for t in scale_table[:-1]:
+        idx -= (s <= t).int()
+    return idx
+
+
+def scale_table(lo: float = 0.11, hi: float = 256, levels: int = 64) -> Tensor:
+    """get_scale_table (models/cnn.py:14-21 region: SCALES_MIN / MAX / LEVELS)"""
+    return torch.exp(torch.linspace(math.log(lo), math.log(hi), levels))
+
+
 # --------------------------------------------------------------------------- model
 def _seq_convs(x, sd, p, idxs, strides=None, final_act=False):
     """conv3x3 (+GELU between) stacks of h_a / cc / lrp. cnn.py:54-127."""
