@@ -87,6 +87,13 @@ def shape_table(run_step, top=24):
         f[0] += ms; f[1] += flop; f[2] += 1
     tot = sum(v[0] for v in agg.values())
     rows = []
+    dump = os.environ.get("ICM_SHAPE_TABLE")     # full table (every shape) as JSON lines, for profiles/
+    if dump:
+        with open(dump, "w") as fh:
+            for label, (ms, flop, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                fh.write(json.dumps({"shape": label, "launches": cnt, "ms": round(ms, 4), "share": round(ms / tot, 4),
+                                     "gflop": round(flop / 1e9, 3), "tflops": round(flop / ms / 1e9, 2) if ms > 0 else 0.0})
+                         + "\n")
     for label, (ms, flop, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
         tf = flop / ms / 1e9 if ms > 0 else 0.0
         rows.append({"shape": label, "launches": cnt, "ms": round(ms, 4), "share": round(ms / tot, 4),

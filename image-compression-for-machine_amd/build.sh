@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 objs=""
 pids=""
-for f in conv_igemm conv_wgrad pointwise entropy winattn; do
+for f in conv_igemm conv_wgrad pointwise entropy winattn winattn_mfma; do
   if [ ! -f build/$f.o ] || [ csrc/$f.hip -nt build/$f.o ] || [ csrc/icm_common.h -nt build/$f.o ] || [ ../include/icm_hip.h -nt build/$f.o ]; then
     rm -f build/$f.o
     $HIPCC $FLAGS -c csrc/$f.hip -o build/$f.o &

@@ -14,6 +14,7 @@
 // The bias gradient (row sums of the small-grid tile) is accumulated by the loader waves for free.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "icm_common.h"
 
 namespace icm {
@@ -42,10 +43,240 @@ struct WgDesc {
   int pe[32];                  // patch offset of pixel 2kp (wave-uniform: scalar loads)
 };
 
-// WS (1x1 problems): every MFMA wave holds ALL TA x TB tiles and takes every 4th pixel pair; the four partial sums
-// are folded through LDS at the end.  96 x 96 tiles fit the codec's
-// channel counts (96 / 192 / 576, 160 / 320) far better than 128 x 128 and keep the four waves balanced (9 tiles).
-template <int TA, int TB, int NACC, bool WS = false>
+// Loader waves (4 of the 8 waves of a workgroup): per pixel tile stage the small-grid tile as [a][pixel] (row stride
+// npx + 1) and the big-grid halo patch as [b][patch] into the LDS buffer the MFMA waves are not reading, one tile
+// ahead; accumulate the fused bias gradient (row sums of the small-grid tile) on the way.
+template <int TA, int TB>
+__device__ __forceinline__ void wgrad_loader(const WgDesc& d, const WgPtrs& G, float* smem, int tid, int lane, int wave,
+                                             int a0, int b0, int split, int niter, int bt, int tg) {
+  const PatchGeom& pg = d.pg;
+  const int npx = 1 << d.lgNPX, grow = npx + 1;
+  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
+  const int bufsz = gs_sz + gb_sz;
+  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+  __builtin_amdgcn_s_setprio(3);   // loaders are latency-critical and issue little: let them win arbitration
+  const int ltid = tid - 256;
+  // fused bias gradient = row sums of the staged small-grid tiles: loader thread r adds row r of the PREVIOUS tile
+  // (complete since the last barrier; the MFMA waves only read it) -- one register, fixed summation order
+  const bool do_bias = G.dbias_ws != nullptr && bt == 0 && tg == 0 && ltid < TA * 32;
+  float bacc = 0.0f;
+  const int OHW = d.OH * d.OW;
+  const int p = ltid & (npx - 1), a_sub = ltid >> d.lgNPX, a_step = 256 >> d.lgNPX;
+  const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
+  for (int it = 0; it <= niter; ++it) {
+    if (do_bias && it > 0) {
+      const float* row = smem + ((it - 1) & 1) * bufsz + ltid * grow;
+      float s0 = 0.0f, s1 = 0.0f;
+      for (int j = 0; j < npx; j += 2) { s0 += row[j]; s1 += row[j + 1]; }
+      bacc += s0 + s1;
+    }
+    if (it < niter) {
+      int q = split + it * d.nsplit;
+      const int tx_i = q % d.tiles_x; q /= d.tiles_x;
+      const int ty_i = q % d.tiles_y;
+      const int tn_i = q / d.tiles_y;
+      const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
+      float* gsT = smem + (it & 1) * bufsz;
+      float* gbP = gsT + gs_sz;
+      const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
+      const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
+      if (d.gs_vec4) {
+        // 16-byte loads: lane handles 4 consecutive pixels of channel (ltid >> lg4) + rows4 * k; npx / 4 lanes per
+        // channel row (16 for 64-pixel tiles, 8 for 32-pixel tiles), rows4 = 256 / (npx / 4) channels per pass
+        const int lg4 = d.lgNPX - 2, rows4 = 256 >> lg4;
+        const int p4 = (ltid & ((1 << lg4) - 1)) << 2;
+        const int tx4 = p4 & TWm, ty4 = (p4 >> d.lgTW) & THm, ti4 = p4 >> (d.lgTW + d.lgTH);
+        const int n4 = n0 + ti4, oy4 = oy0 + ty4, ox4 = ox0 + tx4;
+        const bool pv4 = n4 < pg.N && oy4 < d.OH && ox4 < d.OW;
+        const float* src4 = G.gs + (long long)n4 * d.gs_bs + oy4 * d.OW + ox4;
+        const int a_sub4 = ltid >> lg4;
+        // batches of 6 loads in flight (a full unroll of the 12 / 48 loads of the 192-row tiles spills registers)
+#pragma unroll 1
+        for (int k0 = 0; k0 < TA * 2; k0 += 6) {
+          f32x4 v[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int a = a_sub4 + rows4 * (k0 + u), ca = a0 + a;
+            v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (k0 + u < TA * 2 && a < TA * 32 && pv4 && ca < d.Ca)
+              v[u] = *reinterpret_cast<const f32x4*>(src4 + (long long)ca * OHW);
+          }
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int a = a_sub4 + rows4 * (k0 + u);
+            if (k0 + u < TA * 2 && a < TA * 32) {
+              float* dst = gsT + a * grow + p4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) dst[e] = apply_act(v[u][e], d.act_s);
+            }
+          }
+        }
+      } else {
+      const float* src = G.gs + (long long)n * d.gs_bs + oy * d.OW + ox;
+#pragma unroll 1
+      for (int k0 = 0; k0 < TA * 8; k0 += 16) {   // 16 loads in flight per lane
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int a = a_sub + a_step * (k0 + u), ca = a0 + a;
+          v[u] = (a < TA * 32 && pv && ca < d.Ca) ? src[(long long)ca * OHW] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int a = a_sub + a_step * (k0 + u);
+          if (a < TA * 32) gsT[a * grow + p] = apply_act(v[u], d.act_s);
+        }
+      }
+      }
+      PlaneMap pm;
+      if (pg.vec4) {
+        plane_map_init_v4(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+        stage_planes_v4<8>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+      } else {
+        plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+        stage_planes<12>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+      }
+    }
+    __syncthreads();
+  }
+  if (do_bias && a0 + ltid < d.Ca) G.dbias_ws[(long long)split * d.Ca + a0 + ltid] = bacc;
+}
+
+// ---- single-tap-group kernel with 3 x 3 accumulator tiles per MFMA wave (1x1 problems) ----------------------------
+// Workgroup tile = (TA x TB) 32-tiles of (a, b); the four MFMA waves form a WA x WB x WK grid: wave (wa, wb, wk) holds
+// the 3 x 3 tiles [3 wa, 3 wa + 3) x [3 wb, 3 wb + 3) and takes the pixel pairs kp = wk (mod WK); the WK partial sums
+// are folded through LDS at the end.  96-wide tiles fit the codec's channel counts (96 / 192 / 576; 160 / 320) far
+// better than 128 x 128, and the loaders are latency-bound (a fixed number of bytes in flight per CU), so the FLOPs
+// per staged byte decide the speed: <6,6> (192 x 192 per workgroup) moves half the bytes per FLOP of <3,3>.
+//   <6,6,2,2>  WK = 1   192 x 192   (GDN gamma, proj / conv1x1 of the dim-192 gates, qkv)
+//   <3,6,1,2>  WK = 2    96 x 192   <6,3,2,1>  WK = 2   192 x 96   (ResidualUnit 1x1s, thin-channel ends)
+//   <3,3,1,1>  WK = 4    96 x  96
+template <int TA, int TB, int WA, int WB>
+__global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(TA == 3 * WA && TB == 3 * WB && (WA * WB == 1 || WA * WB == 2 || WA * WB == 4), "3 x 3 tiles per wave");
+  constexpr int WK = 4 / (WA * WB);
+  const PatchGeom& pg = d.pg;
+  const int npx = 1 << d.lgNPX, grow = npx + 1;
+  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
+  const int bufsz = gs_sz + gb_sz;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const WgPtrs G = d.g[blockIdx.y];
+  int bid = blockIdx.x;
+  if (d.xcd_order) {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  const int at = bid % d.natile; bid /= d.natile;
+  const int bt = bid % d.nbtile; bid /= d.nbtile;
+  const int tg = bid % d.ngroups;
+  const int split = bid / d.ngroups;
+  const int a0 = at * TA * 32, b0 = bt * TB * 32, t0 = tg * d.tpg;
+  const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
+  if (wave >= 4) {
+    wgrad_loader<TA, TB>(d, G, smem, tid, lane, wave, a0, b0, split, niter, bt, tg);
+    return;
+  }
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wk = wave_u % WK, wsp = wave_u / WK;
+  const int wa = wsp / WB, wb = wsp % WB;
+  int boffs[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) boffs[u] = ((wb * 3 + u) * 32 + l31) * pg.CS + d.tapoff[t0] + h * d.po_h;
+  f32x16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  const int pe_lane = d.pe[lane & 31];
+  __syncthreads();  // tile 0 staged
+  const int nkp = npx >> 1;   // 16 / 32 pixel pairs per tile: every wave takes nkp / WK of them (an even number)
+  for (int it = 0; it < niter; ++it) {
+    const float* gsT = smem + (it & 1) * bufsz;
+    const float* gbP = gsT + gs_sz;
+    const float* arow = gsT + (wa * 3 * 32 + l31) * grow + h;
+    float avA[3], bvA[3], avB[3], bvB[3];
+    auto fetch = [&](float (&av)[3], float (&bv)[3], int kn) {
+      const int po = __builtin_amdgcn_readlane(pe_lane, kn);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) bv[u] = gbP[boffs[u] + po];
+    };
+    auto mma = [&](const float (&av)[3], const float (&bv)[3]) {
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+          acc[ta * 3 + tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta * 3 + tb], 0, 0, 0);
+    };
+    fetch(avA, bvA, wk);
+    for (int kp = wk; kp < nkp; kp += 2 * WK) {
+      fetch(avB, bvB, min(kp + WK, nkp - 1));
+      mma(avA, bvA);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      fetch(avA, bvA, min(kp + 2 * WK, nkp - 1));
+      if (kp + WK < nkp) mma(avB, bvB);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (WK > 1) {
+    // the WK waves of a (wa, wb) group hold partial sums of the same 9 tiles: fold them through LDS (free after the
+    // last tile barrier; the loaders have left, ended waves do not take part in s_barrier) so that the workgroup
+    // writes ONE slab.  At most two accumulator sets per group are parked at a time (LDS budget).
+    constexpr int SET = 9 * 16 * 64;               // floats of one wave's accumulators
+    constexpr int SLOTS = (WK - 1) < 2 ? (WK - 1) : 2;
+    float* red = smem + wsp * SLOTS * SET;
+#pragma unroll
+    for (int r0 = 1; r0 < WK; r0 += SLOTS) {
+      if (wk >= r0 && wk < r0 + SLOTS) {
+        float* dst = red + (wk - r0) * SET;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64 + lane] = acc[i][r];
+      }
+      __syncthreads();
+      if (wk == 0) {
+        for (int k = 0; k < SLOTS && r0 + k < WK; ++k)
+#pragma unroll
+          for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] += red[k * SET + (i * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+    if (wk != 0) return;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int ta = wa * 3 + i / 3, tb = wb * 3 + i % 3;
+    const int b = b0 + tb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (a < d.Ca && b < pg.C)
+        G.ws[(((long long)split * d.ntaps + t0) * d.Ca + a) * pg.C + b] = acc[i][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- general kernel: accumulators = (tap, a-tile, b-tile) triples dealt to the four MFMA waves ----------------------
+template <int TA, int TB, int NACC>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const PatchGeom& pg = d.pg;
@@ -75,194 +306,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
 
   if (loader) {
-    __builtin_amdgcn_s_setprio(3);   // loaders are latency-critical and issue little: let them win arbitration
-    const int ltid = tid - 256;
-    const bool do_bias = G.dbias_ws != nullptr && bt == 0 && tg == 0;
-    float bsum[TA * 8];
-#pragma unroll
-    for (int k = 0; k < TA * 8; ++k) bsum[k] = 0.0f;
-    const int OHW = d.OH * d.OW;
-    const int p = ltid & (npx - 1), a_sub = ltid >> d.lgNPX, a_step = 256 >> d.lgNPX;
-    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
-    for (int it = 0; it <= niter; ++it) {
-      if (it < niter) {
-        int q = split + it * d.nsplit;
-        const int tx_i = q % d.tiles_x; q /= d.tiles_x;
-        const int ty_i = q % d.tiles_y;
-        const int tn_i = q / d.tiles_y;
-        const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
-        float* gsT = smem + (it & 1) * bufsz;
-        float* gbP = gsT + gs_sz;
-        const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
-        const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
-        if (d.gs_vec4) {
-          // 16-byte loads: lane handles 4 consecutive pixels of channel (ltid >> 4) + 16k
-          const int p4 = (ltid & 15) << 2;
-          const int tx4 = p4 & TWm, ty4 = (p4 >> d.lgTW) & THm, ti4 = p4 >> (d.lgTW + d.lgTH);
-          const int n4 = n0 + ti4, oy4 = oy0 + ty4, ox4 = ox0 + tx4;
-          const bool pv4 = n4 < pg.N && oy4 < d.OH && ox4 < d.OW;
-          const float* src4 = G.gs + (long long)n4 * d.gs_bs + oy4 * d.OW + ox4;
-          const int a_sub4 = ltid >> 4;
-#pragma unroll
-          for (int k = 0; k < TA * 2; ++k) {
-            const int a = a_sub4 + 16 * k, ca = a0 + a;
-            f32x4 v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (pv4 && ca < d.Ca) v = *reinterpret_cast<const f32x4*>(src4 + (long long)ca * OHW);
-            float* dst = gsT + a * grow + p4;
-            float s4 = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float w = apply_act(v[e], d.act_s);
-              dst[e] = w;
-              s4 += w;
-            }
-            bsum[k] += s4;
-          }
-        } else {
-        const float* src = G.gs + (long long)n * d.gs_bs + oy * d.OW + ox;
-#pragma unroll
-        for (int k = 0; k < TA * 8; ++k) {
-          const int a = a_sub + a_step * k, ca = a0 + a;
-          if (a < TA * 32) {
-            float v = 0.0f;
-            if (pv && ca < d.Ca) {
-              v = src[(long long)ca * OHW];
-              v = apply_act(v, d.act_s);
-            }
-            gsT[a * grow + p] = v;
-            bsum[k] += v;
-          }
-        }
-        }
-        PlaneMap pm;
-        if (pg.vec4) {
-          plane_map_init_v4(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-          stage_planes_v4<8>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
-        } else {
-          plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-          stage_planes<12>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
-        }
-      }
-      __syncthreads();
-    }
-    if (do_bias && d.gs_vec4) {
-#pragma unroll
-      for (int k = 0; k < TA * 2; ++k) {
-        float s = bsum[k];
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const int a = (ltid >> 4) + 16 * k, ca = a0 + a;
-        if ((ltid & 15) == 0 && ca < d.Ca) G.dbias_ws[(long long)split * d.Ca + ca] = s;
-      }
-    } else if (do_bias) {
-#pragma unroll
-      for (int k = 0; k < TA * 8; ++k) {
-        float s = bsum[k];
-        for (int o = 32; o > 0; o >>= 1)
-          if (o < npx) s += __shfl_xor(s, o, 64);   // lanes sharing a channel are npx consecutive lanes
-        const int a = a_sub + a_step * k, ca = a0 + a;
-        if (p == 0 && a < TA * 32 && ca < d.Ca) G.dbias_ws[(long long)split * d.Ca + ca] = s;
-      }
-    }
+    wgrad_loader<TA, TB>(d, G, smem, tid, lane, wave, a0, b0, split, niter, bt, tg);
     return;
   }
 
   // ------------------------------------------------------------------ MFMA waves
   const int h = lane >> 5, l31 = lane & 31;
-  if constexpr (WS) {
-    static_assert(NACC == TA * TB, "wave-split mode: one accumulator per tile");
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int boffs[TB];
-#pragma unroll
-    for (int tb = 0; tb < TB; ++tb) boffs[tb] = (tb * 32 + l31) * pg.CS + d.tapoff[t0] + h * d.po_h;
-    f32x16 acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-    const int pe_lane = d.pe[lane & 31];
-    __syncthreads();  // tile 0 staged
-    const int nkp = npx >> 1;   // 32 for the 64-pixel tiles this mode is planned with: 8 pairs per wave
-    for (int it = 0; it < niter; ++it) {
-      const float* gsT = smem + (it & 1) * bufsz;
-      const float* gbP = gsT + gs_sz;
-      const float* arow = gsT + l31 * grow + h;
-      float avA[TA], bvA[TB], avB[TA], bvB[TB];
-      auto fetch = [&](float (&av)[TA], float (&bv)[TB], int kn) {
-        const int po = __builtin_amdgcn_readlane(pe_lane, kn);
-#pragma unroll
-        for (int u = 0; u < TA; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
-#pragma unroll
-        for (int u = 0; u < TB; ++u) bv[u] = gbP[boffs[u] + po];
-      };
-      auto mma = [&](const float (&av)[TA], const float (&bv)[TB]) {
-#pragma unroll
-        for (int ta = 0; ta < TA; ++ta)
-#pragma unroll
-          for (int tb = 0; tb < TB; ++tb)
-            acc[ta * TB + tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta * TB + tb], 0, 0, 0);
-      };
-      fetch(avA, bvA, wave_u);
-      for (int kp = wave_u; kp < nkp; kp += 8) {
-        fetch(avB, bvB, min(kp + 4, nkp - 1));
-        mma(avA, bvA);
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        fetch(avA, bvA, min(kp + 8, nkp - 1));
-        if (kp + 4 < nkp) mma(avB, bvB);
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-      }
-      __syncthreads();
-    }
-    // the four waves hold partial sums of the same 9 tiles: fold them through LDS (free after the last tile barrier;
-    // the loaders have left, ended waves do not take part in s_barrier) so that the workgroup writes ONE slab --
-    // 4x less slab traffic and a 4x shorter reduction.  Two rounds (the staging buffers hold two accumulator sets).
-    float* red = smem;
-    constexpr int SET = NACC * 16 * 64;   // floats of one wave's accumulators
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-      const int src0 = round == 0 ? 1 : 3;          // round 0: waves 1, 2 -> wave 0 ; round 1: wave 3 -> wave 0
-      const int nsrc = round == 0 ? 2 : 1;
-      if (wave_u >= src0 && wave_u < src0 + nsrc) {
-        float* dst = red + (wave_u - src0) * SET;
-#pragma unroll
-        for (int i = 0; i < NACC; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64 + lane] = acc[i][r];
-      }
-      __syncthreads();
-      if (wave_u == 0) {
-        for (int k = 0; k < nsrc; ++k)
-#pragma unroll
-          for (int i = 0; i < NACC; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] += red[k * SET + (i * 16 + r) * 64 + lane];
-      }
-      __syncthreads();
-    }
-    if (wave_u != 0) return;
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-      const int ta = i / TB, tb = i % TB;
-      const int b = b0 + tb * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (a < d.Ca && b < pg.C)
-          G.ws[(((long long)split * d.ntaps + t0) * d.Ca + a) * pg.C + b] = acc[i][r];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return;
-  }
   // accumulator i of this wave: tile q = wave + 4*i -> (tap, ta, tb); all wave-uniform
   const int ntile = nt * TA * TB;
   int boffs[NACC];
@@ -286,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
   // A tile of accumulator i: tile q = wave + 4*i has ta = (q % (TA*TB)) / TB, which is `i` for the 4x4 (1x1-conv)
   // configuration and wave-uniform otherwise (TA*TB divides 4) -> no per-MFMA operand select, one A read per pair
   constexpr bool kPerAcc = (TA * TB == 16);
-  static_assert(WS || (kPerAcc ? (NACC == 4 && TA == 4) : (4 % (TA * TB) == 0)), "tile -> A-row mapping");
+  static_assert(kPerAcc ? (NACC == 4 && TA == 4) : (4 % (TA * TB) == 0), "tile -> A-row mapping");
   constexpr int NA = kPerAcc ? TA : 1;
   const int ta_w = kPerAcc ? 0 : (wave % (TA * TB)) / TB;
   __syncthreads();  // tile 0 staged
@@ -369,38 +418,61 @@ struct RedDesc {
   int Ca, Cb, ntaps, nsplit, nsplit_bias, nwblocks, vec4;
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
-  __shared__ float tile[WG_MAX_TAPS][257];
+  __shared__ __attribute__((aligned(16))) float tile[WG_MAX_TAPS][257];
   const RedPtrs G = d.g[blockIdx.y];
   const int Ca = d.Ca, ntaps = d.ntaps, nsplit = d.nsplit;
-  if ((int)blockIdx.x >= d.nwblocks) {   // bias part
+  if ((int)blockIdx.x >= d.nwblocks) {   // bias part: 16 channels x 16 split lanes per workgroup, combined in lane order
     if (!G.dbias) return;
-    const int a = ((int)blockIdx.x - d.nwblocks) * 256 + threadIdx.x;
-    if (a >= Ca) return;
+    float* part = &tile[0][0];
+    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int a = ((int)blockIdx.x - d.nwblocks) * 16 + pl;
     float s = 0.0f;
-    for (int k = 0; k < d.nsplit_bias; ++k) s += G.dbias_ws[(long long)k * Ca + a];
-    if (G.accum_bias) s += G.dbias[a];
-    G.dbias[a] = s;
+    if (a < Ca)
+      for (int k = sl; k < d.nsplit_bias; k += 16) s += G.dbias_ws[(long long)k * Ca + a];
+    part[sl * 16 + pl] = s;
+    __syncthreads();
+    if (sl == 0 && a < Ca) {
+      float t = part[pl];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) t += part[u * 16 + pl];
+      if (G.accum_bias) t += G.dbias[a];
+      G.dbias[a] = t;
+    }
     return;
   }
   const long long CaCb = (long long)Ca * d.Cb;
   const long long slab = CaCb * ntaps;
-  if (d.vec4) {   // 1x1 problems, 16-byte aligned: thread = 4 consecutive (a, b) positions
-    const long long ab = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (ab >= CaCb) return;
-    const float* p = G.ws + ab;
+  if (d.vec4) {
+    // 1x1 problems, 16-byte aligned.  Workgroup = 16 float4 positions x 16 split lanes: lane sl adds the slabs
+    // k = sl (mod 16) (a few hundred slabs of a 1x1 problem are summed by ~600 workgroups with 1-2 load batches each,
+    // instead of 36 workgroups walking 256 slabs: that walk cost more than the GEMM); the 16 partial sums meet in LDS
+    // and are added in lane order -- deterministic.
+    f32x4* part = reinterpret_cast<f32x4*>(&tile[0][0]);   // [16 split lanes][16 positions]
+    const int pl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long long ab = ((long long)blockIdx.x * 16 + pl) * 4;
     f32x4 s = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    int k = 0;
-    for (; k + 8 <= nsplit; k += 8) {
-      f32x4 v[8];
+    if (ab < CaCb) {
+      const float* p = G.ws + ab;
+      int k = sl;
+      for (; k + 7 * 16 < nsplit; k += 8 * 16) {
+        f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (k + u) * slab);
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (long long)(k + 16 * u) * slab);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < nsplit; k += 16) s += *reinterpret_cast<const f32x4*>(p + (long long)k * slab);
     }
-    for (; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(p + k * slab);
-    f32x4* o = reinterpret_cast<f32x4*>(G.dw + ab);
-    if (G.accum) s += *o;
-    *o = s;
+    part[sl * 16 + pl] = s;
+    __syncthreads();
+    if (sl == 0 && ab < CaCb) {
+      f32x4 t = part[pl];
+#pragma unroll
+      for (int u = 1; u < 16; ++u) t += part[u * 16 + pl];
+      f32x4* o = reinterpret_cast<f32x4*>(G.dw + ab);
+      if (G.accum) t += *o;
+      *o = t;
+    }
     return;
   }
   const long long ab0 = (long long)blockIdx.x * 256;
@@ -433,8 +505,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   }
 }
 
-// test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4>, 3 = <3,3,9,wave-split>;
+// test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4> (general kernel);
+// 3 = t33<3,3,1,1>, 4 = t33<6,6,2,2>, 5 = t33<3,6,1,2>, 6 = t33<6,3,2,1> (3 x 3 tiles per wave, one tap per workgroup);
 // XCD-aware workgroup order 0 / 1; -1 = automatic choice
+#define WG_NVARIANTS 7
 static int g_force_variant = -1, g_force_xcd = -1;
 
 struct WgPlan {
@@ -453,7 +527,11 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
   bool ok = false;
   for (int lg = 6; lg >= 4 && !ok; --lg) {   // pixels per tile: 64, else 32 / 16 for tiny images with big halos
     p.lgNPX = lg;
-    p.lgTW = std::min(std::min(4, lg), ceil_log2(a.OW));
+    // tile width: up to 16 pixels for halo patches (keeps the patch rows short); halo-free (1x1) problems take the
+    // widest rows the image offers -- every channel row of a tile is one contiguous run in memory, and 64-byte runs
+    // (16 pixels) scattered over channel planes use a fraction of what 256-byte runs get from L2 / the memory side
+    const bool halo_free = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    p.lgTW = std::min(std::min(halo_free ? lg : 4, lg), ceil_log2(a.OW));
     p.lgTH = std::min(lg - p.lgTW, ceil_log2(a.OH));
     p.lgTI = lg - p.lgTW - p.lgTH;
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TI = 1 << p.lgTI;
@@ -466,9 +544,21 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       return (size_t)2 * (ta * 32 * ((1 << lg) + 1) + tb * 32 * p.CS) * 4;
     };
     p.ws = 0;
+    auto t33 = [&](int v, int ta, int tb) -> bool {
+      // the fold of the K-split waves parks up to two accumulator sets per (wa, wb) group in the staging LDS
+      const int wk = 4 / ((ta / 3) * (tb / 3));
+      const size_t fold = wk > 1 ? (size_t)(ta / 3) * (tb / 3) * std::min(wk - 1, 2) * 9 * 16 * 64 * 4 : 0;
+      const size_t need = std::max(lds_of(ta, tb), fold);
+      if (need > 160 * 1024) return false;
+      p.ta = ta; p.tb = tb; p.nacc = 9; p.tpg = 1; p.ws = v;
+      return true;
+    };
     auto variant = [&](int v) -> bool {   // kernel variant v for this tile size; false if its LDS does not fit
       switch (v) {
-        case 3: if (lds_of(3, 3) > 150 * 1024) return false; p.ta = 3; p.tb = 3; p.nacc = 9; p.tpg = 1; p.ws = 1; return true;
+        case 3: return t33(3, 3, 3);
+        case 4: return t33(4, 6, 6);
+        case 5: return t33(5, 3, 6);
+        case 6: return t33(6, 6, 3);
         case 2: if (lds_of(4, 4) > 150 * 1024) return false; p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; return true;
         case 1: if (lds_of(2, 2) > 150 * 1024) return false; p.ta = 2; p.tb = 2; p.nacc = 9; p.tpg = std::min(ntaps, 9); return true;
         default:   // <=14 taps per group x 2 a-tiles = 28 tiles = 7 per MFMA wave
@@ -478,16 +568,38 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       }
     };
     if (g_force_variant >= 0) ok = variant(g_force_variant);
-    else if (ntaps == 1 && lds_of(4, 4) <= 150 * 1024) {
-      // 96 x 96 wave-split tiles when they waste less of the padded (a, b) rectangle than 128 x 128
-      const double pad128 = (double)cdiv(a.Ca, 128) * 128 * cdiv(a.Cb, 128) * 128;
-      const double pad96 = (double)cdiv(a.Ca, 96) * 96 * cdiv(a.Cb, 96) * 96;
-      ok = variant((lg == 6 && pad96 * 1.05 <= pad128) ? 3 : 2);
+    else if (ntaps == 1) {
+      // 1x1 problems: the loaders are latency-bound, so time ~ padded MACs x max(1, kappa x staged bytes per MAC);
+      // kappa from the measured 45 TF of the 96 x 96 tile (0.29 of the MFMA peak; profiles/r02_*)
+      static const struct { int v, ta, tb; } cand[] = {{4, 6, 6}, {5, 3, 6}, {6, 6, 3}, {3, 3, 3}, {2, 4, 4}};
+      double bestc = 1e300;
+      int bestv = -1;
+      for (const auto& c : cand) {
+        const size_t need = c.v == 2 ? lds_of(4, 4) : lds_of(c.ta, c.tb);
+        if (need > 160 * 1024) continue;
+        const double area = (double)cdiv(a.Ca, 32 * c.ta) * 32 * c.ta * cdiv(a.Cb, 32 * c.tb) * 32 * c.tb;
+        const double cost = area * std::max(1.0, 5.2 * (1.0 / c.ta + 1.0 / c.tb));
+        if (cost < bestc - 1e-9) { bestc = cost; bestv = c.v; }
+      }
+      ok = bestv >= 0 && variant(bestv);
+      // a smaller pixel tile is only worth it for the big tiles that need it (<6,6> does not fit 64 pixels)
+      if (ok && lg == 6) {
+        const double area6 = (double)cdiv(a.Ca, 32 * p.ta) * 32 * p.ta * cdiv(a.Cb, 32 * p.tb) * 32 * p.tb *
+                             std::max(1.0, 5.2 * (1.0 / p.ta + 1.0 / p.tb));
+        const double area66 = (double)cdiv(a.Ca, 192) * 192 * cdiv(a.Cb, 192) * 192 * std::max(1.0, 5.2 / 3.0);
+        if (area66 < area6 - 1e-9) ok = false;   // retry at lg = 5, where <6,6> fits
+      }
     }
     else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) ok = variant(1);
     else ok = variant(0);
     if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
-    if (ok) p.lds = lds_of(p.ta, p.tb);
+    if (ok) {
+      p.lds = lds_of(p.ta, p.tb);
+      if (p.ws) {
+        const int wk = 4 / ((p.ta / 3) * (p.tb / 3));
+        if (wk > 1) p.lds = std::max(p.lds, (size_t)(p.ta / 3) * (p.tb / 3) * std::min(wk - 1, 2) * 9 * 16 * 64 * 4);
+      }
+    }
   }
   if (!ok) return ICM_ERR_UNSUPPORTED;
   const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TI = 1 << p.lgTI;
@@ -501,7 +613,7 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
   const double slots = 256.0 * occ;
   double best = 1e300;
   p.nsplit = 1;
-  for (int sp = 1; sp <= std::min(p.ntiles, 64); ++sp) {
+  for (int sp = 1; sp <= std::min(p.ntiles, 256); ++sp) {
     const double rounds = std::ceil((double)base * sp / slots);
     const double per = (double)cdiv(p.ntiles, sp) + 0.8;
     const double cost = rounds * per * (1.0 + 0.004 * sp);
@@ -561,9 +673,9 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   pg.H = a->H; pg.W = a->W; pg.N = a->N; pg.C = a->Cb; pg.act = a->act_b; pg.bs = a->gb_bs;
   {
     const int TW = 1 << p.lgTW;
-    bool v4 = ntaps == 1 && a->stride == 1 && a->pad == 0 && p.lgNPX == 6 && (TW % 4) == 0 && (a->W % 4) == 0 &&
+    bool v4 = ntaps == 1 && a->stride == 1 && a->pad == 0 && p.lgNPX >= 5 && (TW % 4) == 0 && (a->W % 4) == 0 &&
               (a->gb_bs % 4) == 0 && ((long long)a->H * a->W % 4) == 0 && (p.PW % 4) == 0 && (p.PP % 4) == 0;
-    bool g4 = p.lgNPX == 6 && (TW % 4) == 0 && (a->OW % 4) == 0 && (a->gs_bs % 4) == 0 &&
+    bool g4 = p.lgNPX >= 5 && (TW % 4) == 0 && (a->OW % 4) == 0 && (a->gs_bs % 4) == 0 &&
               ((long long)a->OH * a->OW % 4) == 0;
     for (int i = 0; i < n; ++i) {
       v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[i].gb) & 15) == 0);
@@ -594,7 +706,10 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ws) fn = wgrad_kernel<3, 3, 9, true>;
+  if (p.ws == 3) fn = wgrad_t33_kernel<3, 3, 1, 1>;
+  else if (p.ws == 4) fn = wgrad_t33_kernel<6, 6, 2, 2>;
+  else if (p.ws == 5) fn = wgrad_t33_kernel<3, 6, 1, 2>;
+  else if (p.ws == 6) fn = wgrad_t33_kernel<6, 3, 2, 1>;
   else if (p.ta == 4) fn = wgrad_kernel<4, 4, 4>;
   else if (p.tb == 2) fn = wgrad_kernel<2, 2, 9>;
   else fn = wgrad_kernel<2, 1, 7>;
@@ -608,18 +723,18 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
     for (int i = 0; i < n; ++i)
       v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[i].ws) & 15) == 0) && ((reinterpret_cast<uintptr_t>(arr[i].dw) & 15) == 0);
     r.vec4 = v4 ? 1 : 0;
-    r.nwblocks = (int)((CaCb + (v4 ? 1023 : 255)) / (v4 ? 1024 : 256));
+    r.nwblocks = (int)((CaCb + (v4 ? 63 : 255)) / (v4 ? 64 : 256));
   }
   bool any_bias = false;
   for (int i = 0; i < n; ++i) any_bias |= arr[i].dbias != nullptr;
-  const int rblocks = r.nwblocks + (any_bias ? cdiv(a->Ca, 256) : 0);
+  const int rblocks = r.nwblocks + (any_bias ? cdiv(a->Ca, 16) : 0);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks, n), dim3(256), 0, stream, r);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
 
 void icm_debug_force_wgrad_cfg(int variant, int xcd_order) {
-  icm::g_force_variant = (variant >= 0 && variant <= 3) ? variant : -1;
+  icm::g_force_variant = (variant >= 0 && variant < WG_NVARIANTS) ? variant : -1;
   icm::g_force_xcd = (xcd_order == 0 || xcd_order == 1) ? xcd_order : -1;
 }
 

@@ -17,6 +17,13 @@
 
 namespace icm {
 
+// matrix-core kernels for 8x8 windows (winattn_mfma.hip): ICM_OK = launched, -1 = geometry not covered
+int winattn_mfma_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W, int heads, int ws,
+                     int shift, hipStream_t stream);
+int winattn_mfma_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable_ws, int N, int C,
+                     int H, int W, int heads, int ws, int shift, hipStream_t stream);
+static int g_force_valu = 0;   // test hook: 1 = always take the generic (VALU) kernels below
+
 struct WaDesc {
   const float* qkv;
   const float* table;
@@ -374,6 +381,8 @@ static int fill_desc(WaDesc& d, int N, int C, int H, int W, int heads, int ws, i
 using namespace icm;
 extern "C" {
 
+void icm_debug_force_winattn_valu(int on) { icm::g_force_valu = on ? 1 : 0; }
+
 int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W, int heads, int ws,
                     int shift, void* stream) {
   if (!qkv || !table || !out) return ICM_ERR_ARG;
@@ -381,6 +390,10 @@ int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int
   int rc = fill_desc(d, N, C, H, W, heads, ws, shift);
   if (rc) return rc;
   d.qkv = qkv; d.table = table; d.out = out;
+  if (!g_force_valu) {
+    const int rm = winattn_mfma_fwd(qkv, table, out, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
+    if (rm >= 0) return rm;
+  }
   WaFn f, b;
   if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
   const int waves = std::min(4, (heads + d.G - 1) / d.G);
@@ -419,16 +432,22 @@ int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, flo
   dtable_plan(N, H, W, heads, ws, nwin, E, S, chunk);
   if (ws_floats < (int64_t)nwin * E + (int64_t)S * E) return ICM_ERR_ARG;
   d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable_ws = wsp;
-  WaFn f, b;
-  if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
-  const int waves = std::min(2, (heads + d.G - 1) / d.G);
   const int tw = 2 * ws - 1;
-  if (tw * tw > d.T * d.hd) return ICM_ERR_UNSUPPORTED;   // the table gradient is accumulated in the dO region
-  const size_t lds = (size_t)waves * d.G * ((3 * d.T * d.hd + d.T * (d.T + 1) + 3) & ~3) * 4;
-  if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(b))) return ICM_ERR_LAUNCH;
-  hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
-  ICM_CHECK_LAUNCH();
+  int rm = -1;
+  if (!g_force_valu)
+    rm = winattn_mfma_bwd(qkv, table, dout, dqkv, wsp, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
+  if (rm > 0) return rm;
+  if (rm < 0) {
+    WaFn f, b;
+    if (!pick(d.hd, f, b)) return ICM_ERR_UNSUPPORTED;
+    const int waves = std::min(2, (heads + d.G - 1) / d.G);
+    if (tw * tw > d.T * d.hd) return ICM_ERR_UNSUPPORTED;   // the table gradient is accumulated in the dO region
+    const size_t lds = (size_t)waves * d.G * ((3 * d.T * d.hd + d.T * (d.T + 1) + 3) & ~3) * 4;
+    if (lds > 160 * 1024) return ICM_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(b))) return ICM_ERR_LAUNCH;
+    hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(64 * waves), lds, (hipStream_t)stream, d);
+    ICM_CHECK_LAUNCH();
+  }
   float* part = wsp + (long long)nwin * E;
   hipLaunchKernelGGL(dtable_reduce1_kernel, dim3((E + 63) / 64, S), dim3(256), 0, (hipStream_t)stream, wsp, part, E,
                      nwin, chunk);

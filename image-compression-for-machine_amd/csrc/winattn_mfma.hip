@@ -1,0 +1,443 @@
+// Window multi-head self-attention core on the matrix cores (8x8 windows: 64 tokens per window), gfx950.
+//
+// One wave = one (window, head): Q^T, K^T, V^T (and dO^T in the backward pass) of the head sit in LDS as [d][token]
+// slabs (row stride 65: the token-major reads of an MFMA A operand are conflict-free, the channel-major reads of a
+// B operand are consecutive), straight from the NCHW qkv tensor -- cyclic shift, window partition and head split are
+// address arithmetic as in winattn.hip.  All contractions are v_mfma_f32_32x32x2_f32 (exact f32):
+//
+//   S^T = K Q^T   (64 x 64, K = hd)      column = query i, so a query's 64 scores live in 32 registers of lanes i and
+//                                        i + 32: the softmax is an in-lane reduction plus one cross-half exchange
+//   O^T = V^T P^T (hd x 64, K = 64)      P^T is used as the MFMA B operand IN PLACE: register r of the accumulator tile
+//                                        holds rows j_r (lanes 0-31) and j_r + 4 (lanes 32-63), exactly the (k = 0, k = 1)
+//                                        pair of a K = 2 step, so the A operand reads V^T[d][j_r + 4 (lane >> 5)] and no
+//                                        probability ever moves between lanes or through memory
+//
+// and the backward pass adds dP^T = V dO^T, dQ^T = K^T dS^T, and -- with the (i, j) roles of the tiles swapped, which
+// the MFMA gives for free by swapping its operands -- S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS.
+// Relative-position-bias gradients: each lane adds its dS entries into the head's LDS table, lanes 0-31 first, then
+// lanes 32-63 (within a half all table entries of one register are distinct), so the sum order is fixed; the
+// per-(window, head) tables go to the same workspace slabs winattn.hip reduces in window order.
+#include "icm_common.h"
+
+namespace icm {
+
+struct WaDesc;   // winattn.hip
+
+struct WmDesc {
+  const float* qkv;
+  const float* table;
+  float* out;          // fwd
+  const float* dout;   // bwd
+  float* dqkv;         // bwd
+  float* dtable_ws;    // bwd
+  int N, C, H, W, heads, shift, nwx, nwy;
+  float scale;
+};
+
+#define WM_WS 8
+#define WM_T 64
+#define WM_TS 65
+#define WM_NTAB 225   // (2 * 8 - 1)^2
+
+__device__ __forceinline__ int wm_region(int s, int L, int shift) { return s < L - WM_WS ? 0 : (s < L - shift ? 1 : 2); }
+
+// pixel offset (oy * W + ox) and shift-mask label of token t of window (wy, wx)
+__device__ __forceinline__ void wm_token(const WmDesc& d, int wy, int wx, int t, int& pix, int& lab) {
+  const int r = t >> 3, c = t & 7;
+  const int sy = wy * WM_WS + r, sx = wx * WM_WS + c;
+  int oy = sy + d.shift, ox = sx + d.shift;
+  if (oy >= d.H) oy -= d.H;
+  if (ox >= d.W) ox -= d.W;
+  pix = oy * d.W + ox;
+  lab = d.shift > 0 ? wm_region(sy, d.H, d.shift) * 3 + wm_region(sx, d.W, d.shift) : 0;
+}
+
+// rows of a 32x32 accumulator tile held by register r of a lane in half h: (r & 3) + 8 (r >> 2) + 4 h
+__device__ __forceinline__ int wm_row(int r) { return (r & 3) + 8 * (r >> 2); }
+// relative-position index of (query i, key j), both 0..63 (win_attention.py:64-74)
+__device__ __forceinline__ int wm_relidx(int i, int j) {
+  return ((i >> 3) - (j >> 3) + WM_WS - 1) * (2 * WM_WS - 1) + ((i & 7) - (j & 7) + WM_WS - 1);
+}
+
+// acc[x][y] (+)= sum_d A^T[d][x-tile rows] * B^T[d][y-tile cols]: rows = tokens of slab `rowT`, cols = tokens of slab
+// `colT` (both [HD][WM_TS]); 2 x 2 tiles, HD / 2 MFMA steps each
+template <int HD>
+__device__ __forceinline__ void wm_tok_tok(const float* __restrict__ rowT, const float* __restrict__ colT, int lane,
+                                           f32x16 (&acc)[2][2]) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < HD / 2; ++ks) {
+    const int off = (2 * ks + h) * WM_TS + l31;
+    const float a0 = rowT[off], a1 = rowT[off + 32], b0 = colT[off], b1 = colT[off + 32];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// out^T[d][y] = sum_x chT[d][x] * M[x][y] with M = acc (rows x in registers, cols y in lanes) used in place as the B
+// operand: ND d-tiles of 32 rows (rows >= HD are computed on clamped addresses and never stored)
+template <int HD, int ND>
+__device__ __forceinline__ void wm_ch_tok(const float* __restrict__ chT, const f32x16 (&M)[2][2], int lane,
+                                          f32x16 (&o)[ND][2]) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][y][r] = 0.0f;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tok = x * 32 + wm_row(r) + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int dd = min(dt * 32 + l31, HD - 1);
+        const float a = chT[dd * WM_TS + tok];
+        o[dt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, M[x][0][r], o[dt][0], 0, 0, 0);
+        o[dt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, M[x][1][r], o[dt][1], 0, 0, 0);
+      }
+    }
+}
+
+// store o^T tiles (rows = head channels d, cols = tokens) to a [*, H*W] channel-plane tensor at channel base `cb`
+template <int HD, int ND>
+__device__ __forceinline__ void wm_store(float* __restrict__ base, long long HW, const int (&pix)[2], int lane,
+                                         const f32x16 (&o)[ND][2], float mul) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dd = dt * 32 + wm_row(r) + 4 * h;
+      if (dd < HD) {
+        base[(long long)dd * HW + pix[0]] = o[dt][0][r] * mul;
+        base[(long long)dd * HW + pix[1]] = o[dt][1][r] * mul;
+      }
+    }
+}
+
+// stage one [HD][64] slab: lane = token
+template <int HD>
+__device__ __forceinline__ void wm_load(const float* __restrict__ src, long long HW, int pix, int lane, float mul,
+                                        float* __restrict__ dst) {
+#pragma unroll 8
+  for (int dd = 0; dd < HD; ++dd) dst[dd * WM_TS + lane] = src[(long long)dd * HW + pix] * mul;
+}
+
+__device__ __forceinline__ float wm_xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// scores -> probabilities in place, S^T orientation: acc[jt][it][r] = score of (key j = jt*32 + row(r) + 4h, query
+// i = it*32 + l31).  Adds bias + mask; returns per-query max / sum through m, l (two queries per lane: it = 0, 1).
+__device__ __forceinline__ void wm_softmax_T(f32x16 (&acc)[2][2], const float* __restrict__ bias, const int (&labq)[2],
+                                             const unsigned char* __restrict__ labs, bool masked, int lane,
+                                             float (&m)[2], float (&linv)[2]) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int i = it * 32 + l31;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + wm_row(r) + 4 * h;
+        float s = acc[jt][it][r] + bias[wm_relidx(i, j)];
+        if (masked && labs[j] != labq[it]) s += -100.0f;
+        acc[jt][it][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, wm_xhalf(mx));
+    float sum = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = expf(acc[jt][it][r] - mx);
+        acc[jt][it][r] = p;
+        sum += p;
+      }
+    sum += wm_xhalf(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jt][it][r] *= inv;
+    m[it] = mx;
+    linv[it] = inv;
+  }
+}
+
+// per-wave LDS: NS slabs [HD][65] + bias table (225, padded to 228) + stats
+template <int HD, int NS>
+struct WmLds {
+  static constexpr int kSlab = HD * WM_TS;
+  static constexpr int kFloats = NS * kSlab + 228 + (NS > 3 ? 228 + 3 * WM_T : 0);
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void winattn_mfma_fwd_kernel(const WmDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned char labs[WM_T];
+  __shared__ int pixs[WM_T];
+  constexpr int ND = (HD + 31) / 32;
+  using LDS = WmLds<HD, 3>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Qt = smem + wave * LDS::kFloats;
+  float* Kt = Qt + LDS::kSlab;
+  float* Vt = Kt + LDS::kSlab;
+  float* bias = Vt + LDS::kSlab;
+  int bid;
+  {   // XCD-aware window order (see winattn.hip)
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  const int wx = bid % d.nwx; bid /= d.nwx;
+  const int wy = bid % d.nwy;
+  const int n = bid / d.nwy;
+  const long long HW = (long long)d.H * d.W;
+  if (tid < WM_T) {
+    int px, lb;
+    wm_token(d, wy, wx, tid, px, lb);
+    pixs[tid] = px;
+    labs[tid] = (unsigned char)lb;
+  }
+  __syncthreads();
+  const int l31 = lane & 31;
+  const int mypix = pixs[lane];
+  const int pix2[2] = {pixs[l31], pixs[32 + l31]};
+  const int labq[2] = {labs[l31], labs[32 + l31]};
+  const float* base = d.qkv + (long long)n * 3 * d.C * HW;
+  const bool masked = d.shift > 0;
+  for (int head = wave; head < d.heads; head += 4) {
+    wm_load<HD>(base + (long long)(head * HD) * HW, HW, mypix, lane, d.scale, Qt);
+    wm_load<HD>(base + (long long)(d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Kt);
+    wm_load<HD>(base + (long long)(2 * d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Vt);
+    for (int e = lane; e < WM_NTAB; e += 64) bias[e] = d.table[e * d.heads + head];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    f32x16 st[2][2];
+    wm_tok_tok<HD>(Kt, Qt, lane, st);           // S^T: rows = keys, cols = queries
+    float m[2], linv[2];
+    wm_softmax_T(st, bias, labq, labs, masked, lane, m, linv);
+    f32x16 o[ND][2];
+    wm_ch_tok<HD, ND>(Vt, st, lane, o);         // O^T = V^T P^T
+    wm_store<HD, ND>(d.out + ((long long)n * d.C + head * HD) * HW, HW, pix2, lane, o, 1.0f);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();            // slabs are rewritten by the next head
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void winattn_mfma_bwd_kernel(const WmDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned char labs[WM_T];
+  __shared__ int pixs[WM_T];
+  constexpr int ND = (HD + 31) / 32;
+  using LDS = WmLds<HD, 4>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* Qt = smem + wave * LDS::kFloats;
+  float* Kt = Qt + LDS::kSlab;
+  float* Vt = Kt + LDS::kSlab;
+  float* Gt = Vt + LDS::kSlab;          // dO^T
+  float* bias = Gt + LDS::kSlab;
+  float* dbias = bias + 228;            // table gradient of this (window, head)
+  float* stat_m = dbias + 228;          // per query: max, 1 / sum, delta = sum_j P dP
+  float* stat_l = stat_m + WM_T;
+  float* stat_d = stat_l + WM_T;
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  const int win = bid;
+  const int wx = bid % d.nwx; bid /= d.nwx;
+  const int wy = bid % d.nwy;
+  const int n = bid / d.nwy;
+  const long long HW = (long long)d.H * d.W;
+  if (tid < WM_T) {
+    int px, lb;
+    wm_token(d, wy, wx, tid, px, lb);
+    pixs[tid] = px;
+    labs[tid] = (unsigned char)lb;
+  }
+  __syncthreads();
+  const int l31 = lane & 31, h = lane >> 5;
+  const int mypix = pixs[lane];
+  const int pix2[2] = {pixs[l31], pixs[32 + l31]};
+  const int labq[2] = {labs[l31], labs[32 + l31]};
+  const float* base = d.qkv + (long long)n * 3 * d.C * HW;
+  float* dbase = d.dqkv + (long long)n * 3 * d.C * HW;
+  const bool masked = d.shift > 0;
+  for (int head = wave; head < d.heads; head += 4) {
+    wm_load<HD>(base + (long long)(head * HD) * HW, HW, mypix, lane, d.scale, Qt);
+    wm_load<HD>(base + (long long)(d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Kt);
+    wm_load<HD>(base + (long long)(2 * d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Vt);
+    wm_load<HD>(d.dout + ((long long)n * d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Gt);
+    for (int e = lane; e < WM_NTAB; e += 64) {
+      bias[e] = d.table[e * d.heads + head];
+      dbias[e] = 0.0f;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // ---- column = query orientation: P^T, dP^T -> delta, dS^T -> table gradient, dQ^T
+    {
+      f32x16 pt[2][2];
+      wm_tok_tok<HD>(Kt, Qt, lane, pt);
+      float m[2], linv[2];
+      wm_softmax_T(pt, bias, labq, labs, masked, lane, m, linv);
+      if (h == 0) {
+        stat_m[l31] = m[0]; stat_m[32 + l31] = m[1];
+        stat_l[l31] = linv[0]; stat_l[32 + l31] = linv[1];
+      }
+      f32x16 dpt[2][2];
+      wm_tok_tok<HD>(Vt, Gt, lane, dpt);          // dP^T[j][i] = sum_d V[j][d] dO[i][d]
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        float del = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) del += pt[jt][it][r] * dpt[jt][it][r];
+        del += wm_xhalf(del);
+        if (h == 0) stat_d[it * 32 + l31] = del;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pt[jt][it][r] *= dpt[jt][it][r] - del;   // dS^T
+      }
+      // table gradient: within one half all (i, j_r) of a register hit distinct entries; halves take turns
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        if (h == hh) {
+#pragma unroll
+          for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int idx = wm_relidx(it * 32 + l31, jt * 32 + wm_row(r) + 4 * h);
+                dbias[idx] += pt[jt][it][r];
+              }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+      }
+      f32x16 o[ND][2];
+      wm_ch_tok<HD, ND>(Kt, pt, lane, o);         // dQ^T[d][i] = sum_j K[j][d] dS[i][j]
+      wm_store<HD, ND>(dbase + (long long)(head * HD) * HW, HW, pix2, lane, o, d.scale);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();              // stats visible to the whole wave
+    // ---- column = key orientation: P, dV^T, dP -> dS, dK^T
+    {
+      f32x16 p[2][2];                             // p[it][jt][r]: query i = it*32 + row(r) + 4h, key j = jt*32 + l31
+      wm_tok_tok<HD>(Qt, Kt, lane, p);
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = it * 32 + wm_row(r) + 4 * h;
+          const float mi = stat_m[i], li = stat_l[i];
+          const int labi = labs[i];
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const int j = jt * 32 + l31;
+            float s = p[it][jt][r] + bias[wm_relidx(i, j)];
+            if (masked && labq[jt] != labi) s += -100.0f;
+            p[it][jt][r] = expf(s - mi) * li;
+          }
+        }
+      {
+        f32x16 o[ND][2];
+        wm_ch_tok<HD, ND>(Gt, p, lane, o);        // dV^T[d][j] = sum_i dO[i][d] P[i][j]
+        wm_store<HD, ND>(dbase + (long long)(2 * d.C + head * HD) * HW, HW, pix2, lane, o, 1.0f);
+      }
+      f32x16 dp[2][2];
+      wm_tok_tok<HD>(Gt, Vt, lane, dp);           // dP[i][j] = sum_d dO[i][d] V[j][d]
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float del = stat_d[it * 32 + wm_row(r) + 4 * h];
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) p[it][jt][r] *= dp[it][jt][r] - del;   // dS
+        }
+      f32x16 o[ND][2];
+      wm_ch_tok<HD, ND>(Qt, p, lane, o);          // dK^T[d][j] = sum_i (scale q)[i][d] dS[i][j]
+      wm_store<HD, ND>(dbase + (long long)(d.C + head * HD) * HW, HW, pix2, lane, o, 1.0f);
+    }
+    {
+      float* slab = d.dtable_ws + ((long long)win * d.heads + head) * WM_NTAB;
+      for (int e = lane; e < WM_NTAB; e += 64) slab[e] = dbias[e];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+typedef void (*WmFn)(const WmDesc);
+static bool wm_pick(int hd, WmFn& f, WmFn& b, size_t& lf, size_t& lb) {
+  switch (hd) {
+#define C_(n)                                               \
+  case n:                                                   \
+    f = winattn_mfma_fwd_kernel<n>;                         \
+    b = winattn_mfma_bwd_kernel<n>;                         \
+    lf = (size_t)4 * WmLds<n, 3>::kFloats * sizeof(float);  \
+    lb = (size_t)4 * WmLds<n, 4>::kFloats * sizeof(float);  \
+    return true;
+    C_(8) C_(16) C_(24) C_(32) C_(48)
+#undef C_
+    default: return false;
+  }
+}
+
+static bool wm_fill(WmDesc& d, int N, int C, int H, int W, int heads, int ws, int shift) {
+  if (ws != WM_WS || heads <= 0 || C % heads || H % ws || W % ws || shift < 0 || shift >= ws) return false;
+  d.N = N; d.C = C; d.H = H; d.W = W; d.heads = heads; d.shift = shift;
+  d.nwx = W / ws; d.nwy = H / ws;
+  d.scale = 1.0f / sqrtf((float)(C / heads));
+  return true;
+}
+
+// returns ICM_OK when the MFMA path took the launch, -1 when this geometry is not covered (caller falls through to
+// the generic kernel of winattn.hip), an ICM_ERR_* code on failure
+int winattn_mfma_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W, int heads, int ws,
+                     int shift, hipStream_t stream) {
+  WmDesc d{};
+  WmFn f, b;
+  size_t lf, lb;
+  if (!wm_fill(d, N, C, H, W, heads, ws, shift) || !wm_pick(C / heads, f, b, lf, lb)) return -1;
+  d.qkv = qkv; d.table = table; d.out = out;
+  if (lf > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(f))) return ICM_ERR_LAUNCH;
+  hipLaunchKernelGGL(f, dim3(N * d.nwy * d.nwx), dim3(256), lf, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+int winattn_mfma_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable_ws, int N, int C,
+                     int H, int W, int heads, int ws, int shift, hipStream_t stream) {
+  WmDesc d{};
+  WmFn f, b;
+  size_t lf, lb;
+  if (!wm_fill(d, N, C, H, W, heads, ws, shift) || !wm_pick(C / heads, f, b, lf, lb)) return -1;
+  d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable_ws = dtable_ws;
+  if (lb > 160 * 1024) return -1;
+  if (lb > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(b))) return ICM_ERR_LAUNCH;
+  hipLaunchKernelGGL(b, dim3(N * d.nwy * d.nwx), dim3(256), lb, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+}  // namespace icm

@@ -72,6 +72,7 @@ SYMBOLS = [
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_wgrad_cfg",
+    "icm_debug_force_winattn_valu",
     "icm_pmf_to_quantized_cdf", "icm_rans_encode_with_indexes", "icm_rans_decode_with_indexes",
     "icm_rans_decoder_create", "icm_rans_decoder_decode", "icm_rans_decoder_destroy",
     "icm_eb_table_bounds", "icm_eb_pmf_table", "icm_gc_table_centers", "icm_gc_pmf_table", "icm_gc_build_indexes",
@@ -130,6 +131,8 @@ def lib():
         L.icm_debug_force_conv_cfg.restype = None
         L.icm_debug_force_wgrad_cfg.argtypes = [i32, i32]
         L.icm_debug_force_wgrad_cfg.restype = None
+        L.icm_debug_force_winattn_valu.argtypes = [i32]
+        L.icm_debug_force_winattn_valu.restype = None
         L.icm_eb_likelihood_fwd.argtypes = [vp, vp, C.POINTER(EbParams), vp, vp, i32, i32, i32, f32, vp]
         L.icm_eb_likelihood_bwd.argtypes = [vp, vp, C.POINTER(EbParams), vp, vp, C.POINTER(EbGrads), i32, i32, i32,
                                             f32, i32, vp]

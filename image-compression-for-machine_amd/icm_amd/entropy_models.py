@@ -264,6 +264,14 @@ class EntropyBottleneck(EntropyModel):
         """entropy_models.py:354-393: per-channel offsets and quantised CDFs of the learned density"""
         if self._offset.numel() > 0 and not force:
             return False
+        offset, pmf, tail, pmf_length, max_length = self._pmf_tables()
+        self._offset = offset
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length)
+        self._cdf_length = pmf_length + 2
+        return True
+
+    def _pmf_tables(self):
+        """device side of update(): (offset [C] int32, pmf [C, L], tail_mass [C, 1], pmf_length [C] int32, L)"""
         dev = self.quantiles.device
         Cc = self.channels
         st = L.stream()
@@ -279,10 +287,7 @@ class EntropyBottleneck(EntropyModel):
         tail = torch.empty(Cc, dtype=torch.float32, device=dev)
         check(L.lib().icm_eb_pmf_table(C.byref(prm), minima.data_ptr(), Cc, max_length, ptr(pmf), ptr(tail), st),
               "eb_pmf_table")
-        self._offset = -minima
-        self._quantized_cdf = self._pmf_to_cdf(pmf, tail.reshape(Cc, 1), pmf_length, max_length)
-        self._cdf_length = pmf_length + 2
-        return True
+        return -minima, pmf, tail.reshape(Cc, 1), pmf_length, max_length
 
     @staticmethod
     def _build_indexes(size):
@@ -371,6 +376,13 @@ class GaussianConditional(EntropyModel):
 
     def update(self):
         """entropy_models.py:598-624: one quantised Gaussian CDF per entry of the scale table"""
+        offset, pmf, tail, pmf_length, max_length = self._pmf_tables()
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length)
+        self._offset = offset
+        self._cdf_length = pmf_length + 2
+
+    def _pmf_tables(self):
+        """device side of update(): (offset [ns] int32, pmf [ns, L], tail_mass [ns, 1], pmf_length [ns] int32, L)"""
         dev = self.scale_table.device
         ns = int(self.scale_table.numel())
         if ns == 0:
@@ -386,9 +398,7 @@ class GaussianConditional(EntropyModel):
         tail = torch.empty(ns, dtype=torch.float32, device=dev)
         check(L.lib().icm_gc_pmf_table(ptr(table), centers.data_ptr(), ns, max_length, ptr(pmf), ptr(tail), st),
               "gc_pmf_table")
-        self._quantized_cdf = self._pmf_to_cdf(pmf, tail.reshape(ns, 1), pmf_length, max_length)
-        self._offset = -centers
-        self._cdf_length = pmf_length + 2
+        return -centers, pmf, tail.reshape(ns, 1), pmf_length, max_length
 
     def build_indexes(self, scales):
         """index of the first table entry >= max(scale, bound) (entropy_models.py:661-666)"""

@@ -61,7 +61,7 @@ class CompressionModel(nn.Module):
         names, params = _named(self)
         return dict(zip(names, [p.detach() for p in params]))
 
-    def _compress_latent(self, tape, P, y):
+    def _compress_latent(self, tape, P, y, debug=None):
         """cnn.py:214-266 from ``y`` on: {"strings": [[y_string], z_strings], "shape": z spatial size}"""
         from .ans import _encode
         codec = {"gc": self.gaussian_conditional, "symbols": {}, "indexes": {}}
@@ -75,6 +75,8 @@ class CompressionModel(nn.Module):
         self.gaussian_conditional._check_cdf_length()
         self.gaussian_conditional._check_offsets_size()
         y_string = _encode(sym, idx, self.gaussian_conditional._tables())
+        if debug is not None:      # tests: the coded symbols / CDF indexes (slice-major, cnn.py:254-255)
+            debug.update(symbols=sym, indexes=idx)
         return {"strings": [[y_string], z_strings], "shape": z.size()[-2:]}
 
     def _decompress_latent(self, tape, P, strings, shape, M):
@@ -583,12 +585,12 @@ class WACNN(CompressionModel):
         return self._update_tables(scale_table, force)
 
     @torch.no_grad()
-    def compress(self, x):
+    def compress(self, x, _debug=None):
         """cnn.py:210-266 -> {"strings": [[y_string], z_strings], "shape": z.shape[-2:]}"""
         _check_codec_input(x)
         P = self._params()
         tape = E.Tape(need_grad=False)
-        return self._compress_latent(tape, P, wacnn_g_a(tape, P, x.contiguous()))
+        return self._compress_latent(tape, P, wacnn_g_a(tape, P, x.contiguous()), _debug)
 
     @torch.no_grad()
     def decompress(self, strings, shape):
@@ -838,12 +840,12 @@ class SymmetricalTransFormer(CompressionModel):
         return self._update_tables(scale_table, force)
 
     @torch.no_grad()
-    def compress(self, x):
+    def compress(self, x, _debug=None):
         """stf.py compress(): analysis transform, then the shared latent coder"""
         _check_codec_input(x)
         P = self._params()
         tape = E.Tape(need_grad=False)
-        return self._compress_latent(tape, P, stf_analysis(tape, P, x.contiguous(), None, self.window_size))
+        return self._compress_latent(tape, P, stf_analysis(tape, P, x.contiguous(), None, self.window_size), _debug)
 
     @torch.no_grad()
     def decompress(self, strings, shape):

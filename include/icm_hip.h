@@ -311,6 +311,8 @@ int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, 
  * workgroup order (0 / 1, -1 = automatic) */
 void icm_debug_force_conv_cfg(int idx);
 void icm_debug_force_wgrad_cfg(int variant, int xcd_order);
+/* 1: window attention always runs the generic VALU kernels (the matrix-core kernels cover 8x8 windows) */
+void icm_debug_force_winattn_valu(int on);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # all-gradient bounds (measured on MI355X: see DESIGN.md 2): L2 error of any tensor relative to the total gradient
 # norm, and the largest element-wise error of any tensor relative to that tensor's largest entry
-GRAD_L2_TOL, GRAD_ELEM_TOL = 1e-4, 2e-4
+GRAD_L2_TOL, GRAD_ELEM_TOL = 5e-5, 2e-4   # measured 5.0e-6 / 2.0e-5
 
 
 def _bench():
@@ -74,7 +74,7 @@ def test_b16_eval_forward_vs_oracle():
     for k in ("bpp_loss", "mse_loss", "loss"):
         e = abs(Lh[k].item() - Lr[k].item()) / abs(Lr[k].item())
         print(f"  {k}: {Lh[k].item():.6f} vs {Lr[k].item():.6f} rel {e:.2e}")
-        assert e < 1e-4, k   # north_star: bpp / R-D loss within 1e-4 relative
+        assert e < 5e-6, k   # measured 1.2e-7 (north_star bound: 1e-4 relative)
 
 
 def test_b16_trainer_steps_vs_oracle():
@@ -99,7 +99,7 @@ def test_b16_trainer_steps_vs_oracle():
         for k, i in (("bpp_loss", 0), ("mse_loss", 1), ("loss", 2)):
             e = abs(scal[i] - Lr[k].item()) / abs(Lr[k].item())
             print(f"  step {it} {k}: {scal[i]:.6f} vs {Lr[k].item():.6f} rel {e:.2e}")
-            assert e < 5e-5, (it, k)
+            assert e < 5e-6, (it, k)     # measured 1.2e-7
         if it == 1:
             hip = {n: tr.flat.gviews[n] for n in main}
             tot, worst_l2, worst_elem, rows = PT.grad_errors(hip, Lr["raw_grads"], main)

@@ -39,32 +39,28 @@ def net():
 
 
 def test_tables_vs_oracle(net):
+    """update(): offsets / lengths exact; the device-computed pmfs equal the oracle's to float noise; the module's CDFs
+    are exactly pmf_to_quantized_cdf of ITS pmfs (the quantiser is chaotic by construction -- the count lost to the
+    integer renormalisation, ~half the table length, lands in the last symbol unless the rounded counts happen to sum
+    to 2^16 -- so tables built from pmfs that differ in the last ulp are compared through their pmfs, not entry by
+    entry; the coder itself is checked byte for byte in tests/test_rans_codec.py)"""
     sd = W.make_wacnn_state_dict()
-    # EntropyBottleneck: offsets / lengths exact; pmfs to float noise; the quantised CDFs differ at most by the count
-    # a last-ulp pmf difference can move
-    off, pmf, tail, plen, mx = O.eb_update_tables(sd)
-    eb = net.entropy_bottleneck
-    assert torch.equal(eb._offset.cpu(), off) and torch.equal(eb._cdf_length.cpu(), plen + 2)
-    ref = _cdf_rows(pmf.numpy(), tail.numpy(), plen.tolist(), mx)
-    got = eb._quantized_cdf.cpu().numpy()
-    assert got.shape == ref.shape
-    d = np.abs(got - ref)
-    print("EB cdf: max |diff|", d.max(), "entries differing", int((d > 0).sum()), "of", d.size)
-    assert d.max() <= 2 and (d > 0).mean() < 0.01
-    for i, n in enumerate((plen + 2).tolist()):
-        row = got[i, :n]
-        assert row[0] == 0 and row[-1] == 65536 and (np.diff(row) > 0).all()
-    # GaussianConditional
-    tab = O.scale_table()
-    gc = net.gaussian_conditional
-    assert torch.equal(gc.scale_table.cpu(), tab)
-    off, pmf, tail, plen, mx = O.gc_update_tables(tab)
-    assert torch.equal(gc._offset.cpu(), off) and torch.equal(gc._cdf_length.cpu(), plen + 2)
-    ref = _cdf_rows(pmf.numpy(), tail.numpy(), plen.tolist(), mx)
-    got = gc._quantized_cdf.cpu().numpy()
-    d = np.abs(got - ref)
-    print("GC cdf: max |diff|", d.max(), "entries differing", int((d > 0).sum()), "of", d.size)
-    assert got.shape == ref.shape and d.max() <= 2 and (d > 0).mean() < 0.01
+    for mod, (off, pmf, tail, plen, mx) in ((net.entropy_bottleneck, O.eb_update_tables(sd)),
+                                            (net.gaussian_conditional, O.gc_update_tables(O.scale_table()))):
+        d_off, d_pmf, d_tail, d_len, d_mx = mod._pmf_tables()
+        assert d_mx == mx and torch.equal(d_off.cpu(), off) and torch.equal(d_len.cpu(), plen)
+        assert torch.equal(mod._offset.cpu(), off) and torch.equal(mod._cdf_length.cpu(), plen + 2)
+        e_p = (d_pmf.cpu() - pmf).abs().max().item()
+        e_t = (d_tail.cpu() - tail).abs().max().item()
+        print(type(mod).__name__, "pmf max abs err", e_p, "tail", e_t)
+        assert e_p < 2e-6 and e_t < 2e-6
+        ref = _cdf_rows(d_pmf.cpu().numpy(), d_tail.cpu().numpy(), plen.tolist(), mx)
+        got = mod._quantized_cdf.cpu().numpy()
+        assert got.shape == ref.shape and (got == ref).all()
+        for i, n in enumerate((plen + 2).tolist()):
+            row = got[i, :n]
+            assert row[0] == 0 and row[-1] == 65536 and (np.diff(row) > 0).all()
+    assert torch.equal(net.gaussian_conditional.scale_table.cpu(), O.scale_table())
 
 
 def test_quantize_dequantize_build_indexes(net):
@@ -106,21 +102,41 @@ def test_wacnn_compress_decompress_round_trip(net, B, H, Wd):
     x = W._u(f"cc.x{B}", (B, 3, H, Wd), 0.0, 1.0).to(DEV)
     with torch.no_grad():
         out = net(x)
-    enc = net.compress(x)
+    dbg = {}
+    enc = net.compress(x, _debug=dbg)
     assert list(enc["shape"]) == [H // 64, Wd // 64] and len(enc["strings"]) == 2
     assert len(enc["strings"][0]) == 1 and len(enc["strings"][1]) == B
     dec = net.decompress(enc["strings"], enc["shape"])
     # the decoder runs the same kernels on the same (decoded) inputs: reconstruction identical to the eval forward
     assert torch.equal(dec["x_hat"], out["x_hat"].clamp(0, 1))
+    # coded size of the y stream == the ideal code length of its symbols under the quantised tables (rANS loses
+    # < 0.01 %), i.e. sum of log2(65536 / width) plus 4 bits per escape nibble, plus the 64-bit final state
+    gc = net.gaussian_conditional
+    cdf, size, off = gc._quantized_cdf.cpu().numpy(), gc._cdf_length.cpu().numpy(), gc._offset.cpu().numpy()
+    sym, idx = dbg["symbols"].astype(np.int64), dbg["indexes"].astype(np.int64)
+    v = sym - off[idx]
+    mx = size[idx] - 2
+    esc = (v < 0) | (v >= mx)
+    raw = np.where(v < 0, -2 * v - 1, 2 * (v - mx))
+    vv = np.where(esc, mx, v)
+    width = cdf[idx, vv + 1] - cdf[idx, vv]
+    bits = np.log2(65536.0 / width).sum()
+    nib = np.zeros_like(raw)
+    r = raw.copy()
+    while (r[esc] > 0).any():
+        nib[esc] += (r[esc] > 0)
+        r[esc] >>= 4
+    bits += 4.0 * (nib[esc] + 1 + nib[esc] // 15).sum()
+    actual = len(enc["strings"][0][0]) * 8
+    print(f"B={B} {H}x{Wd}: y stream {actual} bits, ideal {bits:.0f} bits, escapes {int(esc.sum())} of {sym.size}")
+    assert bits <= actual <= bits * 1.0005 + 96
     nbytes = sum(len(s) for part in enc["strings"] for s in part)
     bpp_actual = nbytes * 8.0 / (B * H * Wd)
     bpp_est = sum((torch.log(l).sum() / (-math.log(2) * B * H * Wd)).item() for l in out["likelihoods"].values())
-    print(f"B={B} {H}x{Wd}: actual {bpp_actual:.4f} bpp vs estimated {bpp_est:.4f} bpp")
-    # estimated rate + the constant per-stream cost (an 8-byte final state each) + the cost of 16-bit tables; formula
-    # (untrained) weights put many latents in the table tails, where the quantised CDF and the escape code deviate from
-    # the ideal -log2(p) in both directions: a 10 % band here (a trained model sits within ~1 %)
-    overhead = (1 + B) * 8 * 8.0 / (B * H * Wd)
-    assert bpp_est * 0.90 <= bpp_actual <= bpp_est * 1.10 + overhead + 0.01
+    # formula (untrained) weights leave many latents beyond the tables: the estimate charges them -log2(1e-9) = 30
+    # bits, the escape code fewer, so the actual size sits BELOW the estimate here (a trained model: within ~1 %)
+    print(f"  actual {bpp_actual:.4f} bpp vs estimated {bpp_est:.4f} bpp")
+    assert 0.5 * bpp_est <= bpp_actual <= 1.05 * bpp_est + 0.05
 
 
 def test_symbols_match_oracle_and_oracle_decodes_our_stream(net):
@@ -153,7 +169,12 @@ def test_inference_helpers_pad_and_crop(net):
     r = utils.inference(net, x[0])
     e = utils.inference_entropy_estimation(net, x[0])
     print("inference:", r, "| estimation:", e)
-    assert abs(r["psnr"] - e["psnr"]) < 1e-3 and r["bpp"] > 0 and abs(r["bpp"] - e["bpp"]) < 0.05 * e["bpp"] + 0.05
+    with torch.no_grad():
+        full = net(xp)["x_hat"]
+    ref_psnr = -10.0 * math.log10(((utils.crop(full.clamp(0, 1), pads) - x) ** 2).mean().item())
+    est_psnr = -10.0 * math.log10(((utils.crop(full, pads) - x) ** 2).mean().item())
+    assert abs(r["psnr"] - ref_psnr) < 1e-3 and abs(e["psnr"] - est_psnr) < 1e-3
+    assert r["bpp"] > 0 and 0.5 * e["bpp"] <= r["bpp"] <= 1.05 * e["bpp"] + 0.05
     # eval-mode forward pads to a multiple of 64 itself and crops x_hat back
     with torch.no_grad():
         o = net(x)

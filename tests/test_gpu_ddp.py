@@ -67,5 +67,5 @@ def test_two_ranks_equal_one_rank_on_the_full_batch():
     err = (r0["p"].double() - p1.double())
     l2 = err.norm().item() / upd.norm().item()
     print(f"2 ranks vs 1 rank: relative L2 error of the 2-step update {l2:.2e}, max abs parameter diff {err.abs().max().item():.2e}")
-    assert l2 < 1e-3 and err.abs().max().item() < 2e-5
+    assert l2 < 3e-4 and err.abs().max().item() < 2e-5     # measured 3.2e-5 / 5.2e-6
     assert (r0["ap"] - tr.flat.ap.cpu()).abs().max().item() < 1e-6

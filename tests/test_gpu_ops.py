@@ -483,12 +483,15 @@ def _wgrad_ref(x, w, b, g, k, s, tr):
 
 
 WG_CASES = [
-    # name, N, Cin, H, W, Cout, k, stride, transposed, variants to force
-    ("wg_c5s2", 3, 40, 36, 20, 72, 5, 2, False, (0, 1, 3)),   # <4,4,4> needs > 160 KB of LDS for a 5x5 stride-2 patch
+    # name, N, Cin, H, W, Cout, k, stride, transposed, variants to force (conv_wgrad.hip: 0-2 general kernel <2,1,7> /
+    # <2,2,9> / <4,4,4>; 3-6 the 3x3-tiles-per-wave kernel <3,3,1,1> / <6,6,2,2> / <3,6,1,2> / <6,3,2,1>)
+    ("wg_c5s2", 3, 40, 36, 20, 72, 5, 2, False, (0, 1, 3)),   # <4,4,4> and the 192-wide tiles need > 160 KB of LDS here
     ("wg_t5s2", 2, 48, 10, 12, 40, 5, 2, True, (0, 1)),
-    ("wg_c3s1", 3, 48, 20, 12, 80, 3, 1, False, (0, 1, 2, 3)),
-    ("wg_c1_96_192", 2, 96, 16, 16, 192, 1, 1, False, (0, 1, 2, 3)),
-    ("wg_c1_130_70", 3, 130, 12, 20, 70, 1, 1, False, (0, 1, 2, 3)),
+    ("wg_c3s1", 3, 48, 20, 12, 80, 3, 1, False, (0, 1, 2, 3, 5, 6)),
+    ("wg_c1_96_192", 2, 96, 16, 16, 192, 1, 1, False, (0, 1, 2, 3, 4, 5, 6)),
+    ("wg_c1_130_70", 3, 130, 12, 20, 70, 1, 1, False, (0, 1, 2, 3, 4, 5, 6)),
+    ("wg_c1_200_400", 2, 200, 8, 24, 400, 1, 1, False, (3, 4, 5, 6)),      # several (a, b) blocks per variant
+    ("wg_c1_192_192_big", 4, 192, 64, 32, 192, 1, 1, False, (-1, 4)),      # the automatic choice (<6,6>, 32-pixel tiles)
     ("wg_c3_tiny", 4, 24, 4, 4, 48, 3, 1, False, (0, 1, 2, 3)),
 ]
 
@@ -613,3 +616,54 @@ def test_gate_golden(golden_dir):
     close(gn, f["grad_norms"], 5e-5, what="grad norms")
     close(gs[1 + names.index("conv_a.0.conv.0.weight")], f["g_first_conv_w"], 5e-5, what="g_first_conv_w")
     close(gs[1 + names.index("conv_b.4.bias")], f["g_last_conv_b"], 5e-5, what="g_last_conv_b")
+
+
+# ------------------------------------------------------------------------------------------ window attention: MFMA vs VALU
+@pytest.mark.parametrize("dim,heads,shift,hw", [(192, 8, 4, 16), (192, 8, 0, 24), (64, 8, 4, 16), (128, 8, 3, 8),
+                                                (256, 8, 4, 16), (384, 8, 4, 8)])
+def test_window_attention_mfma_vs_valu_and_oracle(dim, heads, shift, hw):
+    """8x8 windows: the matrix-core kernels (winattn_mfma.hip: QK^T / PV and all five backward contractions on
+    v_mfma_f32_32x32x2_f32) against the generic VALU kernels on the same inputs, and both against the CPU oracle
+    (win_attention.py:84-115,153-207): output, input gradient, all parameter gradients incl. the bias table"""
+    from icm_amd import _lib, layers
+    d = dev()
+    lib = _lib.lib()
+    tag = f"wm{dim}_{shift}"
+    m = layers.WinBasedAttention(dim=dim, num_heads=heads, window_size=8, shift_size=shift)
+    sd = {}
+    for k, v in m.state_dict().items():
+        leaf = k.rsplit(".", 1)[-1]
+        if not v.dtype.is_floating_point:
+            sd[k] = v
+        elif leaf == "relative_position_bias_table":
+            sd[k] = U(tag + k, v.shape, -0.5, 0.5)
+        elif leaf == "weight":
+            bnd = 1.0 / math.sqrt(int(np.prod(v.shape[1:])))
+            sd[k] = U(tag + k, v.shape, -bnd, bnd) * 1.7
+        else:
+            sd[k] = U(tag + k, v.shape, -0.1, 0.1)
+    m.load_state_dict(sd)
+    x = U(tag + ".x", (2, dim, hw, hw), -1.5, 1.5)
+    g = U(tag + ".g", (2, dim, hw, hw), -1, 1)
+    osd = {"p." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.win_based_attention(xr, osd, "p", heads, 8, shift)
+    names = [n for n, _ in m.named_parameters()]
+    grs = torch.autograd.grad(yr, [xr] + [osd["p." + n] for n in names], g)
+    m = m.to(d)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.icm_debug_force_winattn_valu(mode)
+            xg = x.to(d).requires_grad_(True)
+            y = m(xg)
+            gs = torch.autograd.grad(y, [xg] + [p for _, p in m.named_parameters()], g.to(d))
+            res[mode] = [y] + list(gs)
+    finally:
+        lib.icm_debug_force_winattn_valu(0)
+    for mode in (0, 1):
+        close(res[mode][0], yr, what=f"y mode {mode}")
+        for a, b, n in zip(res[mode][1:], grs, ["x"] + names):
+            close(a, b, 1e-4, what=f"grad {n} mode {mode}")
+    for a, b, n in zip(res[0], res[1], ["y", "x"] + names):
+        close(a, b, 2e-5, what=f"mfma vs valu {n}")

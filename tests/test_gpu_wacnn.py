@@ -179,7 +179,7 @@ def test_train_grads_vs_oracle_small():
     crit = RateDistortionLoss(0.0067)(out, x.cuda())
     crit["loss"].backward()
     assert abs(crit["bpp_loss"].item() - Lr["bpp_loss"].item()) <= 1e-4 * Lr["bpp_loss"].item()
-    assert abs(crit["loss"].item() - Lr["loss"].item()) <= 5e-5 * Lr["loss"].item()
+    assert abs(crit["loss"].item() - Lr["loss"].item()) <= 5e-6 * Lr["loss"].item()
     assert rel(out["x_hat"], o["x_hat"]) < 1e-4
     names = [n for n, _ in net.named_parameters() if not n.endswith(".quantiles")]
     hip = {n: p.grad for n, p in net.named_parameters()}
@@ -189,7 +189,7 @@ def test_train_grads_vs_oracle_small():
     print(f"all {len(rows)} gradients: worst ||d||/total {worst_l2:.2e}, worst element-wise rel {worst_elem:.2e}; "
           f"top: {[(n, f'{e:.1e}') for n, _, _, e in rows[:4]]}")
     assert len(rows) == len(names)
-    assert worst_l2 < 1e-4 and worst_elem < 2e-4
+    assert worst_l2 < 5e-6 and worst_elem < 2e-4   # measured <= 4e-7 / 2.0e-5
 
 
 def test_trainer_two_steps_vs_oracle():
@@ -216,7 +216,7 @@ def test_trainer_two_steps_vs_oracle():
         e = abs(sc[2] - Lr["loss"].item()) / abs(Lr["loss"].item())
         print(f"step {it + 1}: loss {sc[2]:.6f} vs {Lr['loss'].item():.6f} (rel {e:.1e}), flips {fy} {fz}")
         assert fy <= PT.near_half(Lr["out"]["_dbg"]) + 2 and fz == 0
-        assert e < 5e-5
+        assert e < 5e-6    # measured <= 1.2e-7
         P = dict(net.named_parameters())
         l2 = PT.update_l2(P, s, sd, pnames)
         print(f"  relative L2 error of the accumulated update: {l2:.2e}")

@@ -46,9 +46,10 @@ def test_host_planning_entry_points():
     b.KH = b.KW = 1
     b.stride, b.pad = 1, 0
     sizes = {k: L.icm_wgrad_workspace_floats_grouped(ctypes.byref(b), k) for k in (1, 6)}
-    assert sizes[1] == L.icm_wgrad_workspace_floats(ctypes.byref(b)) and sizes[6] > sizes[1]
+    assert sizes[1] == L.icm_wgrad_workspace_floats(ctypes.byref(b)) and sizes[6] != sizes[1]
+    assert all(v > 0 and v % (1536 * 384 + 1536) == 0 for v in sizes.values())   # whole slabs (+ bias partials) per split
     # a workspace that is too small for the launch's split count is refused before anything is launched
-    b.dw, b.ws, b.ws_floats = 1, 1, sizes[1]
+    b.dw, b.ws, b.ws_floats = 1, 1, sizes[6] - 64
     arr = (_lib.WgradArgs * 6)(*[b] * 6)
     assert L.icm_conv_wgrad_grouped(arr, 6, None) == 1
     a.OH = 63  # inconsistent geometry -> rejected like a shape error
