@@ -650,6 +650,8 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
               (bg.CS % 4) == 0 && (bg.PWrow % 4) == 0 && (bg.PP % 4) == 0;
     for (int gi = 0; gi < ngroups; ++gi) v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[gi].x) & 15) == 0);
     pg.vec4 = v4 ? 1 : 0;
+    pg.dma = 0;
+    pg.pipe = 0;
     set_v4_pack(pg);
   }
   d.Cout = a.Cout;

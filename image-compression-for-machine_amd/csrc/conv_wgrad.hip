@@ -80,6 +80,11 @@ __device__ __forceinline__ void wgrad_loader(const WgDesc& d, const WgPtrs& G, f
       float* gbP = gsT + gs_sz;
       const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
       const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
+      PlaneMap pm;
+      if (pg.dma) {   // big-grid patch by LDS-DMA first: it flies while the small-grid tile goes through registers
+        plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+        stage_planes_dma(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4, lane);
+      }
       if (d.gs_vec4) {
         // 16-byte loads: lane handles 4 consecutive pixels of channel (ltid >> lg4) + rows4 * k; npx / 4 lanes per
         // channel row (16 for 64-pixel tiles, 8 for 32-pixel tiles), rows4 = 256 / (npx / 4) channels per pass
@@ -128,13 +133,17 @@ __device__ __forceinline__ void wgrad_loader(const WgDesc& d, const WgPtrs& G, f
         }
       }
       }
-      PlaneMap pm;
-      if (pg.vec4) {
+      if (pg.dma) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the barrier below publishes this stage: DMAs must have landed
+        if (pg.act != ICM_ACT_NONE) act_planes_inplace(pg, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4, lane);
+      } else if (pg.vec4) {
         plane_map_init_v4(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-        stage_planes_v4<8>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        if (pg.pipe) stage_planes_v4<8, true>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        else stage_planes_v4<8, false>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
       } else {
         plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
-        stage_planes<12>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        if (pg.pipe) stage_planes<12, true>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
+        else stage_planes<12, false>(G.gb, pm, pg, b0, TB * 32, gbP, __builtin_amdgcn_readfirstlane(wave) - 4);
       }
     }
     __syncthreads();
@@ -684,6 +693,12 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
     pg.vec4 = v4 ? 1 : 0;
     set_v4_pack(pg);
     d.gs_vec4 = g4 ? 1 : 0;
+    // big-grid operand by LDS-DMA: no activation to apply and a halo patch (the halo-free 16-byte register path moves
+    // 4x the bytes per instruction and is kept); wgrad patches are stored linearly (identity column map, PWrow = PW)
+    static const int dma_on = getenv("ICM_WG_DMA") ? atoi(getenv("ICM_WG_DMA")) : 1;
+    pg.dma = (dma_on && (a->act_b == ICM_ACT_NONE || dma_on > 1) && !v4) ? 1 : 0;   // ICM_WG_DMA=2: also with an activation (post-pass in LDS)
+    static const int pipe_on = getenv("ICM_WG_PIPE") ? atoi(getenv("ICM_WG_PIPE")) : 1;
+    pg.pipe = pipe_on;
   }
   d.Ca = a->Ca; d.OH = a->OH; d.OW = a->OW; d.act_s = a->act_s;
   d.xcd_order = ((long long)a->N * a->OH * a->OW >= 16384) ? 1 : 0;

@@ -126,12 +126,20 @@ __device__ __forceinline__ void wm_store(float* __restrict__ base, long long HW,
     }
 }
 
-// stage one [HD][64] slab: lane = token
-template <int HD>
-__device__ __forceinline__ void wm_load(const float* __restrict__ src, long long HW, int pix, int lane, float mul,
-                                        float* __restrict__ dst) {
-#pragma unroll 8
-  for (int dd = 0; dd < HD; ++dd) dst[dd * WM_TS + lane] = src[(long long)dd * HW + pix] * mul;
+// stage NS [HD][64] slabs (lane = token): ALL loads are issued before the first LDS store -- the wave is alone on its
+// SIMD while it loads, so the NS * HD loads overlap each other instead of completing in small dependent batches
+template <int HD, int NS>
+__device__ __forceinline__ void wm_load_all(const float* const (&src)[NS], long long HW, int pix, int lane, float mul0,
+                                            float* __restrict__ dst0) {
+  float v[NS][HD];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int dd = 0; dd < HD; ++dd) v[k][dd] = src[k][(long long)dd * HW + pix];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int dd = 0; dd < HD; ++dd) dst0[(k * HD + dd) * WM_TS + lane] = k == 0 ? v[k][dd] * mul0 : v[k][dd];
 }
 
 __device__ __forceinline__ float wm_xhalf(float v) { return __shfl_xor(v, 32, 64); }
@@ -187,10 +195,10 @@ struct WmLds {
 template <int HD>
 __global__ __launch_bounds__(256, 2) void winattn_mfma_fwd_kernel(const WmDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ unsigned char labs[WM_T];
-  __shared__ int pixs[WM_T];
   constexpr int ND = (HD + 31) / 32;
   using LDS = WmLds<HD, 3>;
+  int* pixs = reinterpret_cast<int*>(smem + 4 * LDS::kFloats);                     // [64] pixel offset of every token
+  unsigned char* labs = reinterpret_cast<unsigned char*>(pixs + WM_T);             // [64] shift-mask region labels
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Qt = smem + wave * LDS::kFloats;
   float* Kt = Qt + LDS::kSlab;
@@ -220,9 +228,11 @@ __global__ __launch_bounds__(256, 2) void winattn_mfma_fwd_kernel(const WmDesc d
   const float* base = d.qkv + (long long)n * 3 * d.C * HW;
   const bool masked = d.shift > 0;
   for (int head = wave; head < d.heads; head += 4) {
-    wm_load<HD>(base + (long long)(head * HD) * HW, HW, mypix, lane, d.scale, Qt);
-    wm_load<HD>(base + (long long)(d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Kt);
-    wm_load<HD>(base + (long long)(2 * d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Vt);
+    {
+      const float* const srcs[3] = {base + (long long)(head * HD) * HW, base + (long long)(d.C + head * HD) * HW,
+                                    base + (long long)(2 * d.C + head * HD) * HW};
+      wm_load_all<HD, 3>(srcs, HW, mypix, lane, d.scale, Qt);   // Qt | Kt | Vt are consecutive slabs
+    }
     for (int e = lane; e < WM_NTAB; e += 64) bias[e] = d.table[e * d.heads + head];
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -241,10 +251,10 @@ __global__ __launch_bounds__(256, 2) void winattn_mfma_fwd_kernel(const WmDesc d
 template <int HD>
 __global__ __launch_bounds__(256, 1) void winattn_mfma_bwd_kernel(const WmDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ unsigned char labs[WM_T];
-  __shared__ int pixs[WM_T];
   constexpr int ND = (HD + 31) / 32;
   using LDS = WmLds<HD, 4>;
+  int* pixs = reinterpret_cast<int*>(smem + 4 * LDS::kFloats);
+  unsigned char* labs = reinterpret_cast<unsigned char*>(pixs + WM_T);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* Qt = smem + wave * LDS::kFloats;
   float* Kt = Qt + LDS::kSlab;
@@ -281,10 +291,12 @@ __global__ __launch_bounds__(256, 1) void winattn_mfma_bwd_kernel(const WmDesc d
   float* dbase = d.dqkv + (long long)n * 3 * d.C * HW;
   const bool masked = d.shift > 0;
   for (int head = wave; head < d.heads; head += 4) {
-    wm_load<HD>(base + (long long)(head * HD) * HW, HW, mypix, lane, d.scale, Qt);
-    wm_load<HD>(base + (long long)(d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Kt);
-    wm_load<HD>(base + (long long)(2 * d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Vt);
-    wm_load<HD>(d.dout + ((long long)n * d.C + head * HD) * HW, HW, mypix, lane, 1.0f, Gt);
+    {
+      const float* const srcs[4] = {base + (long long)(head * HD) * HW, base + (long long)(d.C + head * HD) * HW,
+                                    base + (long long)(2 * d.C + head * HD) * HW,
+                                    d.dout + ((long long)n * d.C + head * HD) * HW};
+      wm_load_all<HD, 4>(srcs, HW, mypix, lane, d.scale, Qt);   // Qt | Kt | Vt | dO^T are consecutive slabs
+    }
     for (int e = lane; e < WM_NTAB; e += 64) {
       bias[e] = d.table[e * d.heads + head];
       dbias[e] = 0.0f;
@@ -317,7 +329,10 @@ __global__ __launch_bounds__(256, 1) void winattn_mfma_bwd_kernel(const WmDesc d
 #pragma unroll
           for (int r = 0; r < 16; ++r) pt[jt][it][r] *= dpt[jt][it][r] - del;   // dS^T
       }
-      // table gradient: within one half all (i, j_r) of a register hit distinct entries; halves take turns
+      // table gradient into the wave's own LDS table.  Different lanes hit the same entry in different
+      // instructions, so the adds are LDS atomics (plain read-modify-writes may legally be reordered per thread); the
+      // table is private to this wave and, within one instruction, the 32 lanes of a half hit 32 distinct entries
+      // (halves take turns), so the order of every entry's additions is the program order: bitwise reproducible.
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         if (h == hh) {
@@ -328,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void winattn_mfma_bwd_kernel(const WmDesc d
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int idx = wm_relidx(it * 32 + l31, jt * 32 + wm_row(r) + 4 * h);
-                dbias[idx] += pt[jt][it][r];
+                __hip_atomic_fetch_add(dbias + idx, pt[jt][it][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
               }
         }
         __builtin_amdgcn_s_waitcnt(0);
@@ -394,8 +409,8 @@ static bool wm_pick(int hd, WmFn& f, WmFn& b, size_t& lf, size_t& lb) {
   case n:                                                   \
     f = winattn_mfma_fwd_kernel<n>;                         \
     b = winattn_mfma_bwd_kernel<n>;                         \
-    lf = (size_t)4 * WmLds<n, 3>::kFloats * sizeof(float);  \
-    lb = (size_t)4 * WmLds<n, 4>::kFloats * sizeof(float);  \
+    lf = ((size_t)4 * WmLds<n, 3>::kFloats + WM_T + WM_T / 4) * sizeof(float);  \
+    lb = ((size_t)4 * WmLds<n, 4>::kFloats + WM_T + WM_T / 4) * sizeof(float);  \
     return true;
     C_(8) C_(16) C_(24) C_(32) C_(48)
 #undef C_

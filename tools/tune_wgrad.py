@@ -30,6 +30,11 @@ SHAPES = [
     ("3x3 128->64 @16 x10", 16, 128, 16, 16, 64, 3, 1, 10),
     ("3x3 64->32 @16 x10", 16, 64, 16, 16, 32, 3, 1, 10),
     ("3x3 64->32 @16 x2", 16, 64, 16, 16, 32, 3, 1, 2),
+    # virtual-GELU inputs (what most 3x3 / RU layers see in the step): name ends with "gelu"
+    ("3x3 96->96 @64 x6 gelu", 16, 96, 64, 64, 96, 3, 1, 6),
+    ("3x3 224->176 @16 x11 gelu", 16, 224, 16, 16, 176, 3, 1, 11),
+    ("3x3 176->128 @16 x10 gelu", 16, 176, 16, 16, 128, 3, 1, 10),
+    ("1x1 96->192 @64 x6 gelu", 16, 96, 64, 64, 192, 1, 1, 6),
 ]
 
 
@@ -60,7 +65,8 @@ def main():
 
         def run():
             for i in range(grp):
-                E.wgrad_defer(tape, dys[i], xs[i], gws[i], Ca=Ca, Cb=Cb, KH=k, KW=k, stride=s, pad=k // 2, dbias=gbs[i])
+                E.wgrad_defer(tape, dys[i], xs[i], gws[i], Ca=Ca, Cb=Cb, KH=k, KW=k, stride=s, pad=k // 2, dbias=gbs[i],
+                              act_b=_lib.ACT_GELU if name.endswith("gelu") else _lib.ACT_NONE)
             E.flush_wgrads(tape)
         res = {}
         for v in list(range(NV)) + [-1]:
