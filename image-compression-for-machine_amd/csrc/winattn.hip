@@ -22,6 +22,11 @@ int winattn_mfma_fwd(const float* qkv, const float* table, float* out, int N, in
                      int shift, hipStream_t stream);
 int winattn_mfma_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable_ws, int N, int C,
                      int H, int W, int heads, int ws, int shift, hipStream_t stream);
+int winattn_mfma16_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W, int heads, int ws,
+                       int shift, hipStream_t stream);
+int winattn_mfma16_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable_ws, int N,
+                       int C, int H, int W, int heads, int ws, int shift, hipStream_t stream);
+int winattn_mfma16_slabs(int N, int C, int H, int W, int heads, int ws, int shift);
 static int g_force_valu = 0;   // test hook: 1 = always take the generic (VALU) kernels below
 
 struct WaDesc {
@@ -391,7 +396,8 @@ int icm_winattn_fwd(const float* qkv, const float* table, float* out, int N, int
   if (rc) return rc;
   d.qkv = qkv; d.table = table; d.out = out;
   if (!g_force_valu) {
-    const int rm = winattn_mfma_fwd(qkv, table, out, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
+    int rm = winattn_mfma_fwd(qkv, table, out, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
+    if (rm < 0) rm = winattn_mfma16_fwd(qkv, table, out, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
     if (rm >= 0) return rm;
   }
   WaFn f, b;
@@ -434,8 +440,22 @@ int icm_winattn_bwd(const float* qkv, const float* table, const float* dout, flo
   d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable_ws = wsp;
   const int tw = 2 * ws - 1;
   int rm = -1;
-  if (!g_force_valu)
+  if (!g_force_valu) {
     rm = winattn_mfma_bwd(qkv, table, dout, dqkv, wsp, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
+    if (rm < 0) {
+      // 4x4 windows: one table-gradient slab per wave task (four windows), fewer than the per-window slabs planned for
+      const int slabs = winattn_mfma16_slabs(N, C, H, W, heads, ws, shift);
+      if (slabs > 0) {
+        rm = winattn_mfma16_bwd(qkv, table, dout, dqkv, wsp, N, C, H, W, heads, ws, shift, (hipStream_t)stream);
+        if (rm == ICM_OK) {
+          nwin = slabs;
+          S = std::max(1, std::min(64, nwin / 16));
+          chunk = (nwin + S - 1) / S;
+          S = (nwin + chunk - 1) / chunk;
+        }
+      }
+    }
+  }
   if (rm > 0) return rm;
   if (rm < 0) {
     WaFn f, b;

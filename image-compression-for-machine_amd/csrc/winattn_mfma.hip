@@ -456,3 +456,374 @@ int winattn_mfma_bwd(const float* qkv, const float* table, const float* dout, fl
 }
 
 }  // namespace icm
+
+// =====================================================================================================================
+// 4x4 windows (16 tokens): stf's Swin blocks and the dim-320 gates.  v_mfma_f32_16x16x4_f32: one 16 x 16 tile per
+// (window, head) for S^T = K Q^T, ceil(hd / 16) tiles for O^T = V^T P^T -- the probabilities again feed the second
+// product straight from the accumulator registers (C/D: col = lane & 15, row = 4 (lane >> 4) + r, so register r holds
+// rows {r, 4 + r, 8 + r, 12 + r} = the four k-slots of one K = 4 step; the A operand reads V^T[d][4 (lane >> 4) + r]).
+// A wave owns FOUR horizontally adjacent windows: its global loads then cover 16 consecutive pixels per row (64-byte
+// segments instead of the 16-byte rows of a single 4-pixel window); the heads of the four windows go through LDS
+// slabs [window][d][token] (row stride 17), one MFMA sequence per window.
+namespace icm {
+
+#define W4_T 16
+#define W4_TS 17
+#define W4_NTAB 49   // (2 * 4 - 1)^2
+
+struct W4Desc {
+  const float* qkv;
+  const float* table;
+  float* out;
+  const float* dout;
+  float* dqkv;
+  float* dtable_ws;
+  int N, C, H, W, heads, shift, ngx, nwy;   // ngx = groups of 4 windows per row
+  float scale;
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int w4_region(int s, int L, int shift) { return s < L - 4 ? 0 : (s < L - shift ? 1 : 2); }
+
+// acc (+)= sum_d rowT[d][row token] * colT[d][col token] for ONE window slab pair ([HD][17] each)
+template <int HD>
+__device__ __forceinline__ f32x4v w4_tok_tok(const float* __restrict__ rowT, const float* __restrict__ colT, int lane) {
+  const int t = lane & 15, g = lane >> 4;
+  f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int ks = 0; ks < HD / 4; ++ks) {
+    const int off = (4 * ks + g) * W4_TS + t;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rowT[off], colT[off], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// o[dt] = sum_x chT[d][x] * M[x][col]: M's rows x = 4 g + r sit in register r of lane group g
+template <int HD, int ND>
+__device__ __forceinline__ void w4_ch_tok(const float* __restrict__ chT, const f32x4v M, int lane, f32x4v (&o)[ND]) {
+  const int t = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt) {
+    o[dt] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    const int dd = min(dt * 16 + t, HD - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(chT[dd * W4_TS + 4 * g + r], M[r], o[dt], 0, 0, 0);
+  }
+}
+template <int HD, int ND>
+__device__ __forceinline__ void w4_store(float* __restrict__ base, long long HW, int pix, int lane, const f32x4v (&o)[ND],
+                                         float mul) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dd = dt * 16 + 4 * g + r;
+      if (dd < HD) base[(long long)dd * HW + pix] = o[dt][r] * mul;
+    }
+}
+__device__ __forceinline__ float w4_xgroups(float v, bool is_max) {
+  const float a = __shfl_xor(v, 16, 64);
+  v = is_max ? fmaxf(v, a) : v + a;
+  const float b = __shfl_xor(v, 32, 64);
+  return is_max ? fmaxf(v, b) : v + b;
+}
+__device__ __forceinline__ int w4_relidx(int i, int j) { return ((i >> 2) - (j >> 2) + 3) * 7 + ((i & 3) - (j & 3) + 3); }
+
+// per-wave LDS: NS slabs x 4 windows x [HD][17], bias table (49 -> 52), [bwd: table gradient 52, stats 3 x 64]
+template <int HD, int NS>
+struct W4Lds {
+  static constexpr int kSlab = HD * W4_TS;          // one window, one tensor
+  static constexpr int kFloats = NS * 4 * kSlab + 52 + (NS > 3 ? 52 + 3 * 64 : 0);
+};
+
+template <int HD, int NS>
+__device__ __forceinline__ void w4_load_all(const float* const (&src)[NS], long long HW, int pix, int lane, float mul0,
+                                            float* __restrict__ dst0) {
+  // lane = (window w = lane >> 4, token t = lane & 15): slab (k, w) element [d][t]
+  const int w = lane >> 4, t = lane & 15;
+  float v[NS][HD];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int dd = 0; dd < HD; ++dd) v[k][dd] = src[k][(long long)dd * HW + pix];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int dd = 0; dd < HD; ++dd)
+      dst0[((k * 4 + w) * HD + dd) * W4_TS + t] = k == 0 ? v[k][dd] * mul0 : v[k][dd];
+}
+
+// geometry of the wave's four windows: pixel / mask label of (window w, token t) for the lane's own (w, t)
+__device__ __forceinline__ void w4_token(const W4Desc& d, int wy, int gx, int w, int t, int& pix, int& lab, bool& valid) {
+  const int wx = gx * 4 + w;
+  valid = wx * 4 < d.W;
+  const int r = t >> 2, c = t & 3;
+  const int sy = wy * 4 + r, sx = min(wx, d.W / 4 - 1) * 4 + c;
+  int oy = sy + d.shift, ox = sx + d.shift;
+  if (oy >= d.H) oy -= d.H;
+  if (ox >= d.W) ox -= d.W;
+  pix = oy * d.W + ox;
+  lab = d.shift > 0 ? w4_region(sy, d.H, d.shift) * 3 + w4_region(sx, d.W, d.shift) : 0;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void winattn_mfma16_fwd_kernel(const W4Desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ND = (HD + 15) / 16;
+  using LDS = W4Lds<HD, 3>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* slabs = smem + wave * LDS::kFloats;
+  float* bias = slabs + 3 * 4 * LDS::kSlab;
+  // one wave = (group of four windows, head): heads run in parallel waves -- the deep levels have few windows (16 x 16
+  // maps: 64 groups) but many heads (24), and a serial head loop leaves the chip idle
+  const int wt = blockIdx.x * 4 + wave;
+  const int ntask = d.N * d.nwy * d.ngx;
+  if (wt >= ntask * d.heads) return;
+  const int head = wt % d.heads, task = wt / d.heads;
+  const int gx = task % d.ngx;
+  const int wy = (task / d.ngx) % d.nwy;
+  const int n = task / (d.ngx * d.nwy);
+  const long long HW = (long long)d.H * d.W;
+  const int t = lane & 15, g = lane >> 4;
+  int mypix, mylab;
+  bool myvalid;
+  w4_token(d, wy, gx, g, t, mypix, mylab, myvalid);   // load mapping: lane = (window g, token t)
+  const float* base = d.qkv + (long long)n * 3 * d.C * HW;
+  const bool masked = d.shift > 0;
+  {
+    {
+      const float* const srcs[3] = {base + (long long)(head * HD) * HW, base + (long long)(d.C + head * HD) * HW,
+                                    base + (long long)(2 * d.C + head * HD) * HW};
+      w4_load_all<HD, 3>(srcs, HW, mypix, lane, d.scale, slabs);
+    }
+    if (lane < W4_NTAB) bias[lane] = d.table[lane * d.heads + head];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      // compute mapping: lane = (k-slot / row group g, token t) of window w
+      int pixw, labq;
+      bool validw;
+      w4_token(d, wy, gx, w, t, pixw, labq, validw);
+      if (!validw) break;   // wave-uniform: windows beyond the row end (image width not a multiple of 16)
+      const float* Qt = slabs + (0 * 4 + w) * LDS::kSlab;
+      const float* Kt = slabs + (1 * 4 + w) * LDS::kSlab;
+      const float* Vt = slabs + (2 * 4 + w) * LDS::kSlab;
+      f32x4v st = w4_tok_tok<HD>(Kt, Qt, lane);      // S^T: rows = keys j = 4 g + r, col = query i = t
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 4 * g + r;
+        float s = st[r] + bias[w4_relidx(t, j)];
+        if (masked) {
+          int pj, lj; bool vj;
+          w4_token(d, wy, gx, w, j, pj, lj, vj);
+          if (lj != labq) s += -100.0f;
+        }
+        st[r] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = w4_xgroups(mx, true);
+      float sum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[r] = expf(st[r] - mx); sum += st[r]; }
+      sum = w4_xgroups(sum, false);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[r] *= inv;
+      f32x4v o[ND];
+      w4_ch_tok<HD, ND>(Vt, st, lane, o);
+      w4_store<HD, ND>(d.out + ((long long)n * d.C + head * HD) * HW, HW, pixw, lane, o, 1.0f);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(128) void winattn_mfma16_bwd_kernel(const W4Desc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ND = (HD + 15) / 16;
+  using LDS = W4Lds<HD, 4>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* slabs = smem + wave * LDS::kFloats;
+  float* bias = slabs + 4 * 4 * LDS::kSlab;
+  float* dbias = bias + 52;
+  float* stat_m = dbias + 52;       // [64]: per (window, query): max, 1 / sum, delta
+  float* stat_l = stat_m + 64;
+  float* stat_d = stat_l + 64;
+  const int wt = blockIdx.x * 2 + wave;
+  const int ntask = d.N * d.nwy * d.ngx;
+  if (wt >= ntask * d.heads) return;
+  const int head = wt % d.heads, task = wt / d.heads;
+  const int gx = task % d.ngx;
+  const int wy = (task / d.ngx) % d.nwy;
+  const int n = task / (d.ngx * d.nwy);
+  const long long HW = (long long)d.H * d.W;
+  const int t = lane & 15, g = lane >> 4;
+  int mypix, mylab;
+  bool myvalid;
+  w4_token(d, wy, gx, g, t, mypix, mylab, myvalid);
+  const float* base = d.qkv + (long long)n * 3 * d.C * HW;
+  float* dbase = d.dqkv + (long long)n * 3 * d.C * HW;
+  const bool masked = d.shift > 0;
+  {
+    {
+      const float* const srcs[4] = {base + (long long)(head * HD) * HW, base + (long long)(d.C + head * HD) * HW,
+                                    base + (long long)(2 * d.C + head * HD) * HW,
+                                    d.dout + ((long long)n * d.C + head * HD) * HW};
+      w4_load_all<HD, 4>(srcs, HW, mypix, lane, d.scale, slabs);
+    }
+    if (lane < W4_NTAB) { bias[lane] = d.table[lane * d.heads + head]; dbias[lane] = 0.0f; }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      int pixw, labq;
+      bool validw;
+      w4_token(d, wy, gx, w, t, pixw, labq, validw);
+      if (!validw) break;
+      const float* Qt = slabs + (0 * 4 + w) * LDS::kSlab;
+      const float* Kt = slabs + (1 * 4 + w) * LDS::kSlab;
+      const float* Vt = slabs + (2 * 4 + w) * LDS::kSlab;
+      const float* Gt = slabs + (3 * 4 + w) * LDS::kSlab;
+      int labr[4];   // labels of tokens 4 g + r (the row tokens of this lane's accumulator registers)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int pj; bool vj;
+        w4_token(d, wy, gx, w, 4 * g + r, pj, labr[r], vj);
+      }
+      // ---- column = query: P^T, dP^T, delta, dS^T, table gradient, dQ^T
+      {
+        f32x4v pt = w4_tok_tok<HD>(Kt, Qt, lane);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = pt[r] + bias[w4_relidx(t, 4 * g + r)];
+          if (masked && labr[r] != labq) s += -100.0f;
+          pt[r] = s;
+          mx = fmaxf(mx, s);
+        }
+        mx = w4_xgroups(mx, true);
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pt[r] = expf(pt[r] - mx); sum += pt[r]; }
+        sum = w4_xgroups(sum, false);
+        const float inv = 1.0f / sum;
+        const f32x4v dpt = w4_tok_tok<HD>(Vt, Gt, lane);      // dP^T[j][i]
+        float del = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pt[r] *= inv; del += pt[r] * dpt[r]; }
+        del = w4_xgroups(del, false);
+        if (g == 0) { stat_m[w * 16 + t] = mx; stat_l[w * 16 + t] = inv; stat_d[w * 16 + t] = del; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pt[r] *= dpt[r] - del;      // dS^T
+        // table gradient: the 16 lanes of one group hit 16 distinct entries per register; groups take turns (LDS
+        // atomics: cross-lane accumulation needs them, the turn order keeps every entry's sum order fixed)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          if (g == gg) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              __hip_atomic_fetch_add(dbias + w4_relidx(t, 4 * g + r), pt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+          __builtin_amdgcn_s_waitcnt(0);
+          __builtin_amdgcn_wave_barrier();
+        }
+        f32x4v o[ND];
+        w4_ch_tok<HD, ND>(Kt, pt, lane, o);                     // dQ^T
+        w4_store<HD, ND>(dbase + (long long)(head * HD) * HW, HW, pixw, lane, o, d.scale);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      // ---- column = key: P, dV^T, dP, dS, dK^T   (rows = queries i = 4 g + r, col = key j = t)
+      {
+        f32x4v p = w4_tok_tok<HD>(Qt, Kt, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * g + r;
+          float s = p[r] + bias[w4_relidx(i, t)];
+          if (masked && labr[r] != labq) s += -100.0f;          // labq = label of token t (here: the key)
+          p[r] = expf(s - stat_m[w * 16 + i]) * stat_l[w * 16 + i];
+        }
+        {
+          f32x4v o[ND];
+          w4_ch_tok<HD, ND>(Gt, p, lane, o);                    // dV^T
+          w4_store<HD, ND>(dbase + (long long)(2 * d.C + head * HD) * HW, HW, pixw, lane, o, 1.0f);
+        }
+        const f32x4v dp = w4_tok_tok<HD>(Gt, Vt, lane);         // dP[i][j]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] *= dp[r] - stat_d[w * 16 + 4 * g + r];
+        f32x4v o[ND];
+        w4_ch_tok<HD, ND>(Qt, p, lane, o);                      // dK^T
+        w4_store<HD, ND>(dbase + (long long)(d.C + head * HD) * HW, HW, pixw, lane, o, 1.0f);
+      }
+    }
+    if (lane < W4_NTAB) d.dtable_ws[((long long)task * d.heads + head) * W4_NTAB + lane] = dbias[lane];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+typedef void (*W4Fn)(const W4Desc);
+static bool w4_pick(int hd, W4Fn& f, W4Fn& b, size_t& lf, size_t& lb) {
+  switch (hd) {
+#define C_(n)                                                 \
+  case n:                                                     \
+    f = winattn_mfma16_fwd_kernel<n>;                         \
+    b = winattn_mfma16_bwd_kernel<n>;                         \
+    lf = (size_t)4 * W4Lds<n, 3>::kFloats * sizeof(float);    \
+    lb = (size_t)2 * W4Lds<n, 4>::kFloats * sizeof(float);    \
+    return true;
+    C_(8) C_(16) C_(24) C_(32) C_(40)
+#undef C_
+    default: return false;
+  }
+}
+static bool w4_fill(W4Desc& d, int N, int C, int H, int W, int heads, int ws, int shift) {
+  if (ws != 4 || heads <= 0 || C % heads || H % 4 || W % 4 || shift < 0 || shift >= 4) return false;
+  d.N = N; d.C = C; d.H = H; d.W = W; d.heads = heads; d.shift = shift;
+  d.ngx = (W / 4 + 3) / 4; d.nwy = H / 4;
+  d.scale = 1.0f / sqrtf((float)(C / heads));
+  return true;
+}
+
+// number of table-gradient slabs the 4x4 backward writes (one per wave task = group of four windows), or -1
+int winattn_mfma16_slabs(int N, int C, int H, int W, int heads, int ws, int shift) {
+  W4Desc d{};
+  W4Fn f, b;
+  size_t lf, lb;
+  if (!w4_fill(d, N, C, H, W, heads, ws, shift) || !w4_pick(C / heads, f, b, lf, lb) || lb > 160 * 1024) return -1;
+  return N * d.nwy * d.ngx;
+}
+
+int winattn_mfma16_fwd(const float* qkv, const float* table, float* out, int N, int C, int H, int W, int heads, int ws,
+                       int shift, hipStream_t stream) {
+  W4Desc d{};
+  W4Fn f, b;
+  size_t lf, lb;
+  if (!w4_fill(d, N, C, H, W, heads, ws, shift) || !w4_pick(C / heads, f, b, lf, lb) || lf > 160 * 1024) return -1;
+  d.qkv = qkv; d.table = table; d.out = out;
+  if (lf > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(f))) return ICM_ERR_LAUNCH;
+  const int nwt = N * d.nwy * d.ngx * heads;
+  hipLaunchKernelGGL(f, dim3((nwt + 3) / 4), dim3(256), lf, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int winattn_mfma16_bwd(const float* qkv, const float* table, const float* dout, float* dqkv, float* dtable_ws, int N,
+                       int C, int H, int W, int heads, int ws, int shift, hipStream_t stream) {
+  W4Desc d{};
+  W4Fn f, b;
+  size_t lf, lb;
+  if (!w4_fill(d, N, C, H, W, heads, ws, shift) || !w4_pick(C / heads, f, b, lf, lb) || lb > 160 * 1024) return -1;
+  d.qkv = qkv; d.table = table; d.dout = dout; d.dqkv = dqkv; d.dtable_ws = dtable_ws;
+  if (lb > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(b))) return ICM_ERR_LAUNCH;
+  const int nwt = N * d.nwy * d.ngx * heads;
+  hipLaunchKernelGGL(b, dim3((nwt + 1) / 2), dim3(128), lb, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+}  // namespace icm

@@ -619,17 +619,20 @@ def test_gate_golden(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------ window attention: MFMA vs VALU
-@pytest.mark.parametrize("dim,heads,shift,hw", [(192, 8, 4, 16), (192, 8, 0, 24), (64, 8, 4, 16), (128, 8, 3, 8),
-                                                (256, 8, 4, 16), (384, 8, 4, 8)])
-def test_window_attention_mfma_vs_valu_and_oracle(dim, heads, shift, hw):
-    """8x8 windows: the matrix-core kernels (winattn_mfma.hip: QK^T / PV and all five backward contractions on
-    v_mfma_f32_32x32x2_f32) against the generic VALU kernels on the same inputs, and both against the CPU oracle
-    (win_attention.py:84-115,153-207): output, input gradient, all parameter gradients incl. the bias table"""
+@pytest.mark.parametrize("dim,heads,ws,shift,hw", [(192, 8, 8, 4, (16, 16)), (192, 8, 8, 0, (24, 24)), (64, 8, 8, 4, (16, 16)),
+                                                   (128, 8, 8, 3, (8, 8)), (256, 8, 8, 4, (16, 16)), (384, 8, 8, 4, (8, 8)),
+                                                   (320, 8, 4, 2, (16, 16)), (48, 3, 4, 2, (32, 24)), (96, 6, 4, 0, (8, 40)),
+                                                   (192, 12, 4, 1, (12, 20)), (64, 8, 4, 2, (8, 8))])
+def test_window_attention_mfma_vs_valu_and_oracle(dim, heads, ws, shift, hw):
+    """the matrix-core kernels (winattn_mfma.hip: QK^T / PV and all five backward contractions on
+    v_mfma_f32_32x32x2_f32 for 8x8 windows, v_mfma_f32_16x16x4_f32 for 4x4 windows incl. rows whose window count is not a
+    multiple of the four a wave takes) against the generic VALU kernels on the same inputs, and both against the CPU
+    oracle (win_attention.py:84-115,153-207): output, input gradient, all parameter gradients incl. the bias table"""
     from icm_amd import _lib, layers
     d = dev()
     lib = _lib.lib()
-    tag = f"wm{dim}_{shift}"
-    m = layers.WinBasedAttention(dim=dim, num_heads=heads, window_size=8, shift_size=shift)
+    tag = f"wm{dim}_{ws}_{shift}"
+    m = layers.WinBasedAttention(dim=dim, num_heads=heads, window_size=ws, shift_size=shift)
     sd = {}
     for k, v in m.state_dict().items():
         leaf = k.rsplit(".", 1)[-1]
@@ -643,11 +646,11 @@ def test_window_attention_mfma_vs_valu_and_oracle(dim, heads, shift, hw):
         else:
             sd[k] = U(tag + k, v.shape, -0.1, 0.1)
     m.load_state_dict(sd)
-    x = U(tag + ".x", (2, dim, hw, hw), -1.5, 1.5)
-    g = U(tag + ".g", (2, dim, hw, hw), -1, 1)
+    x = U(tag + ".x", (2, dim, hw[0], hw[1]), -1.5, 1.5)
+    g = U(tag + ".g", (2, dim, hw[0], hw[1]), -1, 1)
     osd = {"p." + k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
     xr = x.clone().requires_grad_(True)
-    yr = O.win_based_attention(xr, osd, "p", heads, 8, shift)
+    yr = O.win_based_attention(xr, osd, "p", heads, ws, shift)
     names = [n for n, _ in m.named_parameters()]
     grs = torch.autograd.grad(yr, [xr] + [osd["p." + n] for n in names], g)
     m = m.to(d)
