@@ -160,11 +160,15 @@ __device__ __forceinline__ void wgrad_loader(const WgDesc& d, const WgPtrs& G, f
 //   <6,6,2,2>  WK = 1   192 x 192   (GDN gamma, proj / conv1x1 of the dim-192 gates, qkv)
 //   <3,6,1,2>  WK = 2    96 x 192   <6,3,2,1>  WK = 2   192 x 96   (ResidualUnit 1x1s, thin-channel ends)
 //   <3,3,1,1>  WK = 4    96 x  96
-template <int TA, int TB, int WA, int WB>
+//   <3,3,1,1,TAPW>  96 x 96 x 4 taps: the four waves take four TAPS of a multi-tap (3x3) problem instead of four
+//                  pixel-pair subsets -- one staging of the patch serves four taps, and 96-wide tiles fit the 96 / 192
+//                  channel layers that the 64-wide tiles of the general kernel cover at 56 %
+template <int TA, int TB, int WA, int WB, bool TAPW = false>
 __global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(TA == 3 * WA && TB == 3 * WB && (WA * WB == 1 || WA * WB == 2 || WA * WB == 4), "3 x 3 tiles per wave");
-  constexpr int WK = 4 / (WA * WB);
+  static_assert(!TAPW || WA * WB == 1, "tap-per-wave mode: every wave holds the whole 96 x 96 block");
+  constexpr int WK = TAPW ? 1 : 4 / (WA * WB);
   const PatchGeom& pg = d.pg;
   const int npx = 1 << d.lgNPX, grow = npx + 1;
   const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
@@ -189,11 +193,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
   }
   const int h = lane >> 5, l31 = lane & 31;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wk = wave_u % WK, wsp = wave_u / WK;
+  const int wk = TAPW ? 0 : wave_u % WK, wsp = TAPW ? 0 : wave_u / WK;
   const int wa = wsp / WB, wb = wsp % WB;
+  // tap of this wave: t0 (all waves) or t0 + wave (TAPW; waves past the last tap redo it and do not store)
+  const int nt_g = min(d.tpg, d.ntaps - t0);
+  const int mytap = TAPW ? t0 + min(wave_u, nt_g - 1) : t0;
+  const bool tap_live = !TAPW || wave_u < nt_g;
   int boffs[3];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) boffs[u] = ((wb * 3 + u) * 32 + l31) * pg.CS + d.tapoff[t0] + h * d.po_h;
+  for (int u = 0; u < 3; ++u) boffs[u] = ((wb * 3 + u) * 32 + l31) * pg.CS + d.tapoff[mytap] + h * d.po_h;
   f32x16 acc[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
     }
     if (wk != 0) return;
   }
+  if (!tap_live) return;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     const int ta = wa * 3 + i / 3, tb = wb * 3 + i % 3;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
     for (int r = 0; r < 16; ++r) {
       const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (a < d.Ca && b < pg.C)
-        G.ws[(((long long)split * d.ntaps + t0) * d.Ca + a) * pg.C + b] = acc[i][r];
+        G.ws[(((long long)split * d.ntaps + mytap) * d.Ca + a) * pg.C + b] = acc[i][r];
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -484,27 +493,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
     }
     return;
   }
-  const long long ab0 = (long long)blockIdx.x * 256;
-  const long long ab = ab0 + threadIdx.x;
+  // multi-tap problems: workgroup = 64 (a, b) positions x 4 tap lanes (lane tl sums the taps t = tl (mod 4)); two taps
+  // x up to 8 splits = 16 independent loads in flight per thread.  (One thread per position walking all taps one after
+  // the other -- 25 dependent load batches for a 5x5 -- kept ~100 reductions per step latency-bound: 4 ms per step.)
+  const int pl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const long long ab0 = (long long)blockIdx.x * 64;
+  const long long ab = ab0 + pl;
   const bool valid = ab < CaCb;
-  for (int t = 0; t < ntaps; ++t) {
-    float s0 = 0.0f, s1 = 0.0f;
+  for (int t = tl; t < ntaps; t += 8) {
+    const int t2 = t + 4;
+    float sa = 0.0f, sb = 0.0f;
     if (valid) {
-      const float* p = G.ws + (long long)t * CaCb + ab;
-      int k = 0;
-      for (; k + 8 <= nsplit; k += 8) {
-        float v[8];
+      const float* pa = G.ws + (long long)t * CaCb + ab;
+      const float* pb = G.ws + (long long)(t2 < ntaps ? t2 : t) * CaCb + ab;
+      for (int k = 0; k < nsplit; k += 8) {
+        float va[8], vb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * slab];
-        s0 += (v[0] + v[2]) + (v[4] + v[6]);
-        s1 += (v[1] + v[3]) + (v[5] + v[7]);
+        for (int u = 0; u < 8; ++u) {
+          va[u] = (k + u < nsplit) ? pa[(long long)(k + u) * slab] : 0.0f;
+          vb[u] = (k + u < nsplit) ? pb[(long long)(k + u) * slab] : 0.0f;
+        }
+        sa += ((va[0] + va[1]) + (va[2] + va[3])) + ((va[4] + va[5]) + (va[6] + va[7]));
+        sb += ((vb[0] + vb[1]) + (vb[2] + vb[3])) + ((vb[4] + vb[5]) + (vb[6] + vb[7]));
       }
-      for (; k < nsplit; ++k) s0 += p[k * slab];
     }
-    tile[t][threadIdx.x] = s0 + s1;
+    tile[t][pl] = sa;
+    if (t2 < ntaps) tile[t2][pl] = sb;
   }
   __syncthreads();
-  const int nv = (int)min((long long)256, CaCb - ab0);
+  const int nv = (int)min((long long)64, CaCb - ab0);
   float* o = G.dw + ab0 * ntaps;
   for (int e = threadIdx.x; e < nv * ntaps; e += 256) {
     const int abl = e / ntaps, t = e - abl * ntaps;
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
 // test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4> (general kernel);
 // 3 = t33<3,3,1,1>, 4 = t33<6,6,2,2>, 5 = t33<3,6,1,2>, 6 = t33<6,3,2,1> (3 x 3 tiles per wave, one tap per workgroup);
 // XCD-aware workgroup order 0 / 1; -1 = automatic choice
-#define WG_NVARIANTS 7
+#define WG_NVARIANTS 8   /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems) */
 static int g_force_variant = -1, g_force_xcd = -1;
 
 struct WgPlan {
@@ -568,6 +585,10 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
         case 4: return t33(4, 6, 6);
         case 5: return t33(5, 3, 6);
         case 6: return t33(6, 6, 3);
+        case 7:   // 96 x 96 (a, b) block, four taps per workgroup (one per MFMA wave), no K split
+          if (lds_of(3, 3) > 160 * 1024) return false;
+          p.ta = 3; p.tb = 3; p.nacc = 9; p.tpg = std::min(ntaps, 4); p.ws = 7;
+          return true;
         case 2: if (lds_of(4, 4) > 150 * 1024) return false; p.ta = 4; p.tb = 4; p.nacc = 4; p.tpg = 1; return true;
         case 1: if (lds_of(2, 2) > 150 * 1024) return false; p.ta = 2; p.tb = 2; p.nacc = 9; p.tpg = std::min(ntaps, 9); return true;
         default:   // <=14 taps per group x 2 a-tiles = 28 tiles = 7 per MFMA wave
@@ -599,12 +620,18 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
         if (area66 < area6 - 1e-9) ok = false;   // retry at lg = 5, where <6,6> fits
       }
     }
-    else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) ok = variant(1);
+    else if (ntaps <= 9 && lds_of(2, 2) <= 150 * 1024) {
+      // 3x3: 64 x 64 x 9-tap tiles, unless 96-wide tiles fit the channel counts so much better (96 / 192 channels:
+      // 100 % against 56 %) that idling the waves without a tap in the last tap group (9 taps = 4 + 4 + 1) still wins
+      const double pad64 = (double)cdiv(a.Ca, 64) * 64 * cdiv(a.Cb, 64) * 64;
+      const double pad96 = (double)cdiv(a.Ca, 96) * 96 * cdiv(a.Cb, 96) * 96 * (4.0 * cdiv(ntaps, 4) / ntaps);
+      ok = (ntaps > 1 && pad96 * 1.1 < pad64 && variant(7)) || variant(1);
+    }
     else ok = variant(0);
     if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
     if (ok) {
       p.lds = lds_of(p.ta, p.tb);
-      if (p.ws) {
+      if (p.ws && p.ws != 7) {
         const int wk = 4 / ((p.ta / 3) * (p.tb / 3));
         if (wk > 1) p.lds = std::max(p.lds, (size_t)(p.ta / 3) * (p.tb / 3) * std::min(wk - 1, 2) * 9 * 16 * 64 * 4);
       }
@@ -721,7 +748,8 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ws == 3) fn = wgrad_t33_kernel<3, 3, 1, 1>;
+  if (p.ws == 7) fn = wgrad_t33_kernel<3, 3, 1, 1, true>;
+  else if (p.ws == 3) fn = wgrad_t33_kernel<3, 3, 1, 1>;
   else if (p.ws == 4) fn = wgrad_t33_kernel<6, 6, 2, 2>;
   else if (p.ws == 5) fn = wgrad_t33_kernel<3, 6, 1, 2>;
   else if (p.ws == 6) fn = wgrad_t33_kernel<6, 3, 2, 1>;
@@ -738,7 +766,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
     for (int i = 0; i < n; ++i)
       v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[i].ws) & 15) == 0) && ((reinterpret_cast<uintptr_t>(arr[i].dw) & 15) == 0);
     r.vec4 = v4 ? 1 : 0;
-    r.nwblocks = (int)((CaCb + (v4 ? 63 : 255)) / (v4 ? 64 : 256));
+    r.nwblocks = (int)((CaCb + 63) / 64);   // 16 float4 positions (1x1) or 64 positions (multi-tap) per workgroup
   }
   bool any_bias = false;
   for (int i = 0; i < n; ++i) any_bias |= arr[i].dbias != nullptr;
