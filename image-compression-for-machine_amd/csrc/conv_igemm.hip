@@ -19,131 +19,9 @@
 //     PixelShuffle store, gradient accumulation).
 #include <cstdlib>
 #include <vector>
-#include "icm_common.h"
+#include "conv_common.h"
 
 namespace icm {
-
-#define ICM_MAX_TAPS 32
-#define ICM_MAX_GROUPS 12   /* problems of identical geometry per launch (blockIdx.y): the independent slice chains */
-
-struct ConvPtrs {
-  const float* x;
-  const float* wp;
-  const float* bias;
-  float* y;
-  const float* res;
-  const float* aux;
-  const float* aux2;
-  float* y2;
-};
-
-struct ConvDesc {
-  ConvPtrs g[ICM_MAX_GROUPS];
-  long long y_bs, res_bs, aux_bs, aux2_bs, y2_bs;
-  PatchGeom pg;                // input tensor + LDS patch layout
-  int Cout, OHf, OWf;
-  int OHv, OWv;
-  int out_sy, out_oy, out_sx, out_ox;
-  int iy0, ix0;
-  int ntaps;
-  int lgTW, lgTH, lgTI;
-  int tiles_x, tiles_y, tiles_n;
-  int ncot, nchunks8, ckm, ncb;
-  int epi, accum, ps2;
-  int tapoff[ICM_MAX_TAPS];   // dword entries: read with s_load (a 16-bit entry forces a VMEM load + vmcnt(0))
-};
-
-// Epilogue of one 32x32 accumulator tile.  The fused-neighbour kind is a template parameter so that the 16 rows
-// form ONE basic block: all operand loads (bias, residual, aux, old value) are issued back to back and waited for
-// once, instead of a load -> wait -> store chain per element.
-template <int EPI, int half>
-__device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot, int h,
-                                             int n, int oy, int ox, bool pvalid) {
-  const int plane = d.OHf * d.OWf;
-  constexpr bool kRes = EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU || EPI == ICM_EPI_RES_MUL_DGELU;
-  constexpr bool kAux = EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN || EPI == ICM_EPI_MUL_DGELU ||
-                        EPI == ICM_EPI_AXPY2 || EPI == ICM_EPI_LRP || EPI == ICM_EPI_RES_MUL_DGELU;
-  float* yb = P.y + n * d.y_bs;
-  const float* resb = kRes ? P.res + n * d.res_bs : nullptr;
-  const float* auxb = kAux ? P.aux + n * d.aux_bs : nullptr;
-  const float* aux2b = (EPI == ICM_EPI_AXPY2) ? P.aux2 + n * d.aux2_bs : nullptr;
-  float* y2b = P.y2 ? P.y2 + n * d.y2_bs : nullptr;
-  const bool has_bias = P.bias != nullptr;
-  // rows in two halves of 8: bounds the live registers of the load batch (the kernel's VGPR budget sets occupancy)
-  {
-    int off[8];
-    bool ok[8];
-    float bv[8], rv[8], av[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int r = half * 8 + q;
-      const int co = cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      ok[q] = pvalid && co < d.Cout;
-      off[q] = d.ps2 ? (co >> 2) * plane + (oy * 2 + ((co >> 1) & 1)) * d.OWf + ox * 2 + (co & 1)
-                     : co * plane + oy * d.OWf + ox;
-      bv[q] = (has_bias && ok[q]) ? P.bias[co] : 0.0f;
-      if constexpr (kRes) rv[q] = ok[q] ? resb[off[q]] : 0.0f;
-      if constexpr (kAux) av[q] = ok[q] ? auxb[off[q]] : 0.0f;
-      if constexpr (EPI == ICM_EPI_AXPY2) rv[q] = ok[q] ? aux2b[off[q]] : 0.0f;
-    }
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      v[q] = acc[half * 8 + q] + bv[q];
-      if constexpr (EPI == ICM_EPI_RES) v[q] += rv[q];
-      if constexpr (EPI == ICM_EPI_RES_GELU) v[q] += gelu_f(rv[q]);
-      if constexpr (EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN) {
-        if (y2b && ok[q]) y2b[off[q]] = v[q];
-        v[q] = av[q] * (EPI == ICM_EPI_GDN ? rsqrtf(v[q]) : sqrtf(v[q]));
-      }
-      if constexpr (EPI == ICM_EPI_MUL_DGELU) v[q] *= dgelu_f(av[q]);
-      if constexpr (EPI == ICM_EPI_RES_MUL_DGELU) v[q] = (v[q] + rv[q]) * dgelu_f(av[q]);
-      if constexpr (EPI == ICM_EPI_AXPY2) v[q] = rv[q] + 2.0f * av[q] * v[q];
-      if constexpr (EPI == ICM_EPI_LRP) {
-        const float t = tanhf(v[q]);
-        if (y2b && ok[q]) y2b[off[q]] = t;
-        v[q] = av[q] + 0.5f * t;
-      }
-    }
-    if (d.accum) {   // gradient accumulation: one more batched read of the destination
-      float old[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) old[q] = ok[q] ? yb[off[q]] : 0.0f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] += old[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (ok[q]) yb[off[q]] = v[q];
-  }
-}
-template <int EPI>
-__device__ __forceinline__ void store_tile_e(const ConvDesc& d, const ConvPtrs& P, const f32x16 acc, int cot, int h,
-                                             int n, int oy, int ox, bool pvalid) {
-  store_half_e<EPI, 0>(d, P, acc, cot, h, n, oy, ox, pvalid);
-  store_half_e<EPI, 1>(d, P, acc, cot, h, n, oy, ox, pvalid);
-}
-
-// all tiles of one MFMA wave for one epilogue kind (the kind is dispatched once, outside the unrolled tile loops)
-template <int EPI, int TCO, int TPX>
-__device__ __forceinline__ void epilogue_all(const ConvDesc& d, const ConvPtrs& P, const f32x16 (&acc)[TCO][TPX], int cot0,
-                                             int wpx, int h, int l31, int n0, int oy0, int ox0) {
-  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
-#pragma unroll
-  for (int tp = 0; tp < TPX; ++tp) {
-    const int p = (wpx * TPX + tp) * 32 + l31;
-    const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
-    const int n = n0 + ti, oyv = oy0 + ty, oxv = ox0 + tx;
-    const bool pvalid = (n < d.pg.N) && (oyv < d.OHv) && (oxv < d.OWv);
-    const int oy = oyv * d.out_sy + d.out_oy, ox = oxv * d.out_sx + d.out_ox;
-#pragma unroll
-    for (int a = 0; a < TCO; ++a) {
-      const int cot = cot0 + a;
-      if (cot < d.ncot) store_tile_e<EPI>(d, P, acc[a][tp], cot, h, n, oy, ox, pvalid);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
 
 // 512 threads: waves 0-3 issue MFMAs only (B fragments from LDS, A fragments = packed weights from L2);
 // waves 4-7 are loaders that stage the NEXT K-chunk's halo patch into the other LDS buffer meanwhile.
@@ -353,20 +231,21 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][0][r] += red[k * 1024 + r * 64 + lane];
   }
-  // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h.  The epilogue kind is
-  // dispatched ONCE (uniform branch) around the fully unrolled tile loops.
-  switch (d.epi) {
-    case ICM_EPI_RES: epilogue_all<ICM_EPI_RES, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_RES_GELU: epilogue_all<ICM_EPI_RES_GELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_GDN: epilogue_all<ICM_EPI_GDN, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_IGDN: epilogue_all<ICM_EPI_IGDN, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_MUL_DGELU: epilogue_all<ICM_EPI_MUL_DGELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_AXPY2: epilogue_all<ICM_EPI_AXPY2, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_LRP: epilogue_all<ICM_EPI_LRP, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
-    case ICM_EPI_RES_MUL_DGELU:
-      epilogue_all<ICM_EPI_RES_MUL_DGELU, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0);
-      break;
-    default: epilogue_all<ICM_EPI_NONE, TCO, TPX>(d, P, acc, cot0, wpx, h, l31, n0, oy0, ox0); break;
+  // ---- epilogue: D[row = co][col = pixel]; lane holds column l31, rows (r&3)+8*(r>>2)+4*h
+  {
+    int pn[TPX], poy[TPX], pox[TPX];
+    bool pv[TPX];
+#pragma unroll
+    for (int tp = 0; tp < TPX; ++tp) {
+      const int p = (wpx * TPX + tp) * 32 + l31;
+      const int tx = p & TWm, ty = (p >> d.lgTW) & THm, ti = p >> (d.lgTW + d.lgTH);
+      const int oyv = oy0 + ty, oxv = ox0 + tx;
+      pn[tp] = n0 + ti;
+      pv[tp] = (pn[tp] < d.pg.N) && (oyv < d.OHv) && (oxv < d.OWv);
+      poy[tp] = oyv * d.out_sy + d.out_oy;
+      pox[tp] = oxv * d.out_sx + d.out_ox;
+    }
+    epilogue_dispatch<TCO, TPX>(d, P, acc, cot0, h, pn, poy, pox, pv);
   }
 }
 
@@ -548,6 +427,8 @@ static const KernelCfg kCfgs[] = {
 };
 static int g_force_cfg = -1;
 
+static int g_force_1x1 = getenv("ICM_CONV_1X1") ? atoi(getenv("ICM_CONV_1X1")) : -1;   // -1 auto, 0 never, 1 whenever eligible
+
 struct Geometry {
   int lgTW, lgTH, lgTI, PH, PW, PWh, PWrow, PP, CS, tiles_x, tiles_y, tiles_n, ckm;
   size_t lds_bytes;
@@ -590,6 +471,10 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   const int ncot = cdiv(a.Cout, 32), nchunks8 = cdiv(a.Cin, 8);
   const int ntaps = (int)cls.taps.size();
   if (ntaps > ICM_MAX_TAPS) return ICM_ERR_UNSUPPORTED;
+  if (ntaps == 1 && S_in == 1 && out_s == 1 && cls.iy0 == 0 && cls.ix0 == 0) {
+    const int rc = (g_force_cfg >= 0) ? -1 : run_conv1x1(arr, ngroups, wp_off, g_force_1x1, stream);
+    if (rc >= 0) return rc;
+  }
 
   // pick the tile configuration: time ~ rounds x (co-resident workgroups share the MFMA pipes: occ x MFMAs per wave /
   // efficiency + one fixed prologue/epilogue overhead per round), rounds = ceil(workgroups / (256 CUs x occ)); occ = 2
@@ -766,6 +651,7 @@ int icm_convT2d_fwd(const icm_conv_args* a, void* stream) {
 }
 
 void icm_debug_force_conv_cfg(int idx) { icm::g_force_cfg = idx; }
+void icm_debug_force_conv1x1(int mode) { icm::g_force_1x1 = mode; }
 
 int64_t icm_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
   return (int64_t)icm::cdiv(Cin, 8) * KH * KW * icm::cdiv(Cout, 32) * 256;

@@ -71,7 +71,8 @@ SYMBOLS = [
     "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
-    "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_wgrad_cfg",
+    "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_conv1x1",
+    "icm_debug_force_wgrad_cfg",
     "icm_debug_force_winattn_valu",
     "icm_pmf_to_quantized_cdf", "icm_rans_encode_with_indexes", "icm_rans_decode_with_indexes",
     "icm_rans_decoder_create", "icm_rans_decoder_decode", "icm_rans_decoder_destroy",
@@ -129,6 +130,8 @@ def lib():
         L.icm_winattn_bwd_workspace_floats.restype = i64
         L.icm_debug_force_conv_cfg.argtypes = [i32]
         L.icm_debug_force_conv_cfg.restype = None
+        L.icm_debug_force_conv1x1.argtypes = [i32]
+        L.icm_debug_force_conv1x1.restype = None
         L.icm_debug_force_wgrad_cfg.argtypes = [i32, i32]
         L.icm_debug_force_wgrad_cfg.restype = None
         L.icm_debug_force_winattn_valu.argtypes = [i32]

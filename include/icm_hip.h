@@ -310,6 +310,9 @@ int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, 
  * kernel variant (0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4>, 3 = <3,3,9> wave-split; -1 = automatic) and its XCD-aware
  * workgroup order (0 / 1, -1 = automatic) */
 void icm_debug_force_conv_cfg(int idx);
+/* pointwise (1x1 stride-1, Cin % 8 == 0) convolutions: -1 = automatic (the barrier-free direct-operand kernel when the
+ * launch has >= 1024 waves), 0 = always the LDS-staged kernel, 1 = the direct kernel whenever eligible */
+void icm_debug_force_conv1x1(int mode);
 void icm_debug_force_wgrad_cfg(int variant, int xcd_order);
 /* 1: window attention always runs the generic VALU kernels (the matrix-core kernels cover 8x8 windows) */
 void icm_debug_force_winattn_valu(int on);

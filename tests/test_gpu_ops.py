@@ -674,3 +674,76 @@ def test_window_attention_mfma_vs_valu_and_oracle(dim, heads, ws, shift, hw):
     if len(modes) == 2:
         for a, b, n in zip(res[0], res[1], ["y", "x"] + names):
             close(a, b, 2e-5, what=f"mfma vs valu {n}")
+
+
+# ------------------------------------------------------------------------------------------ pointwise (1x1) direct kernel
+P1_CASES = [
+    # name, N, Cin, H, W, Cout  (Cin % 8 == 0; ragged pixel counts, co tails, every co-tile configuration)
+    ("p1_192_192", 2, 192, 16, 16, 192),     # <6,1>
+    ("p1_96_160", 3, 96, 9, 7, 160),         # <5,1>, N*H*W = 189: ragged last strip
+    ("p1_48_128", 2, 48, 8, 8, 128),         # <4,1>
+    ("p1_192_96", 2, 192, 12, 20, 96),       # <3,2>
+    ("p1_8_48", 5, 8, 5, 5, 48),             # <2,2>, one chunk, co tail (48 = 32 + 16)
+    ("p1_24_20", 1, 24, 6, 11, 20),          # <1,2>, three chunks (not a multiple of the prefetch depth)
+    ("p1_320_576", 1, 320, 8, 8, 576),       # <6,1> x 3 co blocks, 40 chunks
+]
+
+
+@pytest.mark.parametrize("case", P1_CASES, ids=[c[0] for c in P1_CASES])
+def test_conv1x1_direct_kernel(case):
+    """the barrier-free pointwise kernel (forced on: these sizes are below its automatic threshold) against torch
+    and against the LDS-staged kernel: forward, input gradient (runs as a transposed 1x1), weight / bias gradient"""
+    from icm_amd import _lib, layers
+    name, N, Cin, H, Wd, Cout = case
+    d = dev()
+    lib = _lib.lib()
+    w = U(name + ".w", (Cout, Cin, 1, 1), -0.2, 0.2)
+    b = U(name + ".b", (Cout,), -0.5, 0.5)
+    x = U(name + ".x", (N, Cin, H, Wd), -1.0, 1.0)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br)
+    g = U(name + ".g", yr.shape, -1.0, 1.0)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], g)
+    out = {}
+    try:
+        for mode in (1, 0):
+            lib.icm_debug_force_conv1x1(mode)
+            m = layers.Conv2d(Cin, Cout, kernel_size=1).to(d)
+            with torch.no_grad():
+                m.weight.copy_(w)
+                m.bias.copy_(b)
+            xg = x.to(d).requires_grad_(True)
+            y = m(xg)
+            gx, gw, gb = torch.autograd.grad(y, [xg, m.weight, m.bias], g.to(d))
+            out[mode] = (y, gx)
+            close(y, yr, what=f"y mode{mode}")
+            close(gx, gxr, what=f"dx mode{mode}")
+            close(gw, gwr, what=f"dw mode{mode}")
+            close(gb, gbr, what=f"db mode{mode}")
+    finally:
+        lib.icm_debug_force_conv1x1(-1)
+    close(out[1][0], out[0][0].cpu(), what="direct vs staged y", tol=2e-6)
+    close(out[1][1], out[0][1].cpu(), what="direct vs staged dx", tol=2e-6)
+
+
+@pytest.mark.parametrize("which", ["gate192", "gate320", "gdn", "igdn", "gate_golden"])
+def test_conv1x1_direct_kernel_fused_neighbours(which, golden_dir):
+    """every fused prologue / epilogue the 1x1 convolutions of the model use (virtual GELU operand, x^2 operand,
+    residual (+GELU), GDN / IGDN normalisation, GELU' and AXPY2 backward epilogues, gradient accumulation) through the
+    direct kernel: the oracle / golden comparisons of the gate and GDN tests, re-run with the kernel forced on"""
+    from icm_amd import _lib
+    lib = _lib.lib()
+    try:
+        lib.icm_debug_force_conv1x1(1)
+        if which == "gate192":
+            test_attention_gate_vs_oracle(192, 8, 4, 16)
+        elif which == "gate320":
+            test_attention_gate_vs_oracle(320, 4, 2, 8)
+        elif which == "gdn":
+            test_gdn_192_vs_oracle(False)
+        elif which == "igdn":
+            test_gdn_192_vs_oracle(True)
+        else:
+            test_gate_golden(golden_dir)
+    finally:
+        lib.icm_debug_force_conv1x1(-1)
