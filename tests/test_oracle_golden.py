@@ -178,8 +178,9 @@ def test_wacnn_end_to_end_eval(golden_dir):
 
 
 def test_round_override_is_transparent():
-    """tests/_parity.py: an oracle run that ADOPTS rounding decisions equal to its own reproduces the free run bit for
-    bit (values and gradients), and a changed decision moves y_hat by exactly one step"""
+    """tests/_parity.py: an oracle run that ADOPTS rounding decisions equal to its own reproduces the free run (values bit
+    for bit; gradients to 1e-6 relative -- the threaded CPU conv backward does not fix its summation order between two
+    runs), and a changed decision moves y_hat by exactly one step"""
     sd = W.make_wacnn_state_dict()
     x = W._u("ro.x", (1, 3, 64, 64), 0.0, 1.0)
     noise = {"z": W._u("ro.nz", (1, 192, 1, 1), -0.5, 0.5), "y": W._u("ro.ny", (1, 320, 4, 4), -0.5, 0.5)}
@@ -196,7 +197,7 @@ def test_round_override_is_transparent():
     o1, s1 = run(ro)
     assert torch.equal(o0["x_hat"], o1["x_hat"]) and torch.equal(o0["likelihoods"]["y"], o1["likelihoods"]["y"])
     for k in ("g_a.0.weight", "g_s.8.bias", "lrp_transforms.9.8.weight", "h_a.0.weight"):
-        assert torch.equal(s0[k].grad, s1[k].grad), k
+        torch.testing.assert_close(s0[k].grad, s1[k].grad, rtol=1e-6, atol=1e-9 + 1e-6 * float(s0[k].grad.abs().max()), msg=k)
     ro2 = {"y": ro["y"].clone(), "z": ro["z"]}
     ro2["y"][0, 300, 1, 2] += 1.0          # slice 9: nothing downstream re-rounds
     o2, _ = run(ro2)
