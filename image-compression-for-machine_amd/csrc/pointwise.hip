@@ -512,6 +512,34 @@ __global__ void pad2d_kernel(const float* __restrict__ src, int N, int C, int H,
   }
 }
 
+// ---------------------------------------------------------------- zigzag block ordering (stf6.py:654-762)
+// The latent [B, C, H, W] is a grid of ns x nH x nW contiguous blocks ([B, ns, C/ns, nH, H/nH, nW, W/nW] view); the
+// zigzag tensor [B, N, C/ns, H/nH, W/nW] lists them in shell order (blk[n] = (c * nH + h) * nW + w of output block n).
+// Pure index permutation, HBM-bound: one element per thread, both sides read / written in runs of W/nW floats.
+struct ZigzagDesc {
+  int blk[64];
+};
+__global__ void zigzag_kernel(const float* __restrict__ src, float* __restrict__ dst, long long x_bs, int B, int N, int Cs,
+                              int nH, int Hb, int nW, int Wb, int reverse, const ZigzagDesc d) {
+  const long long total = (long long)B * N * Cs * Hb * Wb;
+  const int H = nH * Hb, W = nW * Wb;
+  GRID_STRIDE(i, total) {
+    const int q = (int)(i % Wb);
+    long long t = i / Wb;
+    const int r = (int)(t % Hb);
+    t /= Hb;
+    const int cs = (int)(t % Cs);
+    t /= Cs;
+    const int n = (int)(t % N);
+    const long long b = t / N;
+    const int id = d.blk[n];
+    const int w = id % nW, h = (id / nW) % nH, c = id / (nW * nH);
+    const long long xo = b * x_bs + ((long long)(c * Cs + cs) * H + h * Hb + r) * W + w * Wb + q;
+    if (reverse) dst[xo] = src[i];
+    else dst[i] = src[xo];
+  }
+}
+
 // ---------------------------------------------------------------- R-D loss
 // stage 1: per-workgroup partial sums of (squared error, log lik_y, log lik_z) into ws[3][nblk];
 // stage 2 (one workgroup): adds the partials in block order and forms bpp / mse / loss.  Deterministic.
@@ -815,6 +843,46 @@ int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, 
                      OW, top, left, value);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
+}
+// Block order of ZigzagSplits / ZigzagReverse (stf6.py:671-696, 733-758): shell i = blocks whose largest index is i;
+// inside a shell the channel-group index runs fastest, then the row-half index, then the column-half index.
+int icm_zigzag_order(int num_slices, int num_h, int num_w, int32_t* order, int capacity) {
+  if (num_slices <= 0 || num_h <= 0 || num_w <= 0) return -1;
+  const int total = num_slices * num_h * num_w;
+  if (!order) return total;
+  if (capacity < total) return -1;
+  int n = 0;
+  const int shells = std::max(num_slices, std::max(num_h, num_w));
+  for (int i = 0; i < shells; ++i)
+    for (int w = 0; w < std::min(i + 1, num_w); ++w)
+      for (int h = 0; h < std::min(i + 1, num_h); ++h)
+        for (int c = 0; c < std::min(i + 1, num_slices); ++c)
+          if (std::max(c, std::max(h, w)) == i) order[n++] = (c * num_h + h) * num_w + w;
+  return n;
+}
+static int zigzag_run(const float* src, float* dst, int64_t x_bs, int B, int C, int H, int W, int ns, int nh, int nw,
+                      int reverse, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || ns <= 0 || nh <= 0 || nw <= 0) return ICM_ERR_ARG;
+  if (C % ns || H % nh || W % nw) return ICM_ERR_ARG;   // the reference's view() (stf6.py:664) needs exact blocks
+  if (ns * nh * nw > 64) return ICM_ERR_UNSUPPORTED;
+  ZigzagDesc d;
+  int32_t ord[64];
+  const int N = icm_zigzag_order(ns, nh, nw, ord, 64);
+  if (N != ns * nh * nw) return ICM_ERR_ARG;
+  for (int i = 0; i < 64; ++i) d.blk[i] = i < N ? ord[i] : 0;
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(zigzag_kernel, dim3(grid_for(total)), dim3(256), 0, ST, src, dst, (long long)x_bs, B, N, C / ns, nh,
+                     H / nh, nw, W / nw, reverse, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_zigzag_splits(const float* x, int64_t x_bs, float* z, int B, int C, int H, int W, int num_slices, int num_h,
+                      int num_w, void* stream) {
+  return zigzag_run(x, z, x_bs, B, C, H, W, num_slices, num_h, num_w, 0, stream);
+}
+int icm_zigzag_reverse(const float* z, float* x, int64_t x_bs, int B, int C, int H, int W, int num_slices, int num_h,
+                       int num_w, void* stream) {
+  return zigzag_run(z, x, x_bs, B, C, H, W, num_slices, num_h, num_w, 1, stream);
 }
 int icm_rd_loss_fwd(const float* x, const float* x_hat, int64_t n_img_elems, const float* lik_y, int64_t n_y,
                     const float* lik_z, int64_t n_z, int64_t num_pixels, float lmbda, float* out, float* ws,

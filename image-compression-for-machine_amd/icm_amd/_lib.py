@@ -74,6 +74,7 @@ SYMBOLS = [
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_conv1x1",
     "icm_debug_force_wgrad_cfg",
     "icm_debug_force_winattn_valu",
+    "icm_zigzag_order", "icm_zigzag_splits", "icm_zigzag_reverse",
     "icm_pmf_to_quantized_cdf", "icm_rans_encode_with_indexes", "icm_rans_decode_with_indexes",
     "icm_rans_decoder_create", "icm_rans_decoder_decode", "icm_rans_decoder_destroy",
     "icm_eb_table_bounds", "icm_eb_pmf_table", "icm_gc_table_centers", "icm_gc_pmf_table", "icm_gc_build_indexes",
@@ -169,6 +170,9 @@ def lib():
         L.icm_dequantize.argtypes = [vp, vp, i64, i64, i64, vp, i64, i32, i32, i32, vp]
         L.icm_clamp.argtypes = [vp, i64, f32, f32, vp]
         L.icm_pad2d.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, f32, vp]
+        L.icm_zigzag_order.argtypes = [i32, i32, i32, vp, i32]
+        L.icm_zigzag_splits.argtypes = [vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.icm_zigzag_reverse.argtypes = [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]
         _lib = L
     return _lib
 

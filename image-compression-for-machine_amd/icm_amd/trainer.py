@@ -173,6 +173,43 @@ class Trainer:
     def params(self) -> Dict[str, torch.Tensor]:
         return self.flat.views
 
+    def optimizer_state(self):
+        """(optimizer, aux_optimizer) checkpoint entries (train.py:521-523): Adam moments per parameter NAME (independent
+        of the flat-buffer layout), the step count and the learning rates"""
+        f = self.flat
+
+        def pack(items, m, v, pad):
+            out_m, out_v, o = {}, {}, 0
+            for n, prm in items:
+                k = prm.numel()
+                out_m[n] = m[o:o + k].view(prm.shape).detach().cpu().clone()
+                out_v[n] = v[o:o + k].view(prm.shape).detach().cpu().clone()
+                o += (k + 3) // 4 * 4 if pad else k
+            return out_m, out_v
+        m, v = pack(f.main, f.m, f.v, True)
+        am, av = pack(f.aux, f.am, f.av, False)
+        return ({"m": m, "v": v, "step": self.step_no, "lr": self.lr},
+                {"m": am, "v": av, "step": self.step_no, "lr": self.aux_lr})
+
+    def load_optimizer_state(self, opt, aux=None) -> None:
+        f = self.flat
+
+        def unpack(items, m, v, sd, pad):
+            o = 0
+            for n, prm in items:
+                k = prm.numel()
+                if n not in sd["m"] or tuple(sd["m"][n].shape) != tuple(prm.shape):
+                    raise ValueError(f"optimizer state: missing or mis-shaped entry for {n}")
+                m[o:o + k].view(prm.shape).copy_(sd["m"][n])
+                v[o:o + k].view(prm.shape).copy_(sd["v"][n])
+                o += (k + 3) // 4 * 4 if pad else k
+        unpack(f.main, f.m, f.v, opt, True)
+        self.step_no = int(opt["step"])
+        self.lr = float(opt.get("lr", self.lr))
+        if aux is not None:
+            unpack(f.aux, f.am, f.av, aux, False)
+            self.aux_lr = float(aux.get("lr", self.aux_lr))
+
     def step(self, x: torch.Tensor, noise: Optional[dict] = None, drops: Optional[dict] = None) -> torch.Tensor:
         """one training iteration on this rank's shard x [B,3,H,W]; returns the device tensor
         [bpp, mse, loss, sumlog_y, sumlog_z, grad_sqnorm, aux_loss, -] (no host sync)."""

@@ -59,9 +59,9 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 @torch.no_grad()
-def inference(model, x: torch.Tensor) -> Dict[str, float]:
-    """eval_model/__main__.py:96-139 without the file output: actual bit-stream size and reconstruction quality of one
-    image x [3,H,W] or [1,3,H,W] in [0,1]"""
+def inference(model, x: torch.Tensor, recon=None) -> Dict[str, float]:
+    """eval_model/__main__.py:96-139: actual bit-stream size and reconstruction quality of one image x [3,H,W] or
+    [1,3,H,W] in [0,1]; ``recon(x_hat)`` (optional) receives the cropped reconstruction (the reference saves it, :130)"""
     if x.dim() == 3:
         x = x.unsqueeze(0)
     xp, pads = pad_to_multiple(x, 64)
@@ -73,13 +73,15 @@ def inference(model, x: torch.Tensor) -> Dict[str, float]:
     torch.cuda.synchronize() if x.is_cuda else None
     t2 = time.time()
     x_hat = crop(dec["x_hat"], pads)
+    if recon is not None:
+        recon(x_hat)
     num_pixels = x.size(0) * x.size(2) * x.size(3)
     bpp = sum(len(s[0]) for s in enc["strings"]) * 8.0 / num_pixels
     return {"psnr": psnr(x, x_hat), "bpp": bpp, "encoding_time": t1 - t0, "decoding_time": t2 - t1}
 
 
 @torch.no_grad()
-def inference_entropy_estimation(model, x: torch.Tensor) -> Dict[str, float]:
+def inference_entropy_estimation(model, x: torch.Tensor, recon=None) -> Dict[str, float]:
     """eval_model/__main__.py:143-225: forward pass with estimated rates (no entropy coder)"""
     if x.dim() == 3:
         x = x.unsqueeze(0)
@@ -89,6 +91,8 @@ def inference_entropy_estimation(model, x: torch.Tensor) -> Dict[str, float]:
     torch.cuda.synchronize() if x.is_cuda else None
     dt = time.time() - t0
     x_hat = crop(out["x_hat"], pads)
+    if recon is not None:
+        recon(x_hat)
     num_pixels = x.size(0) * x.size(2) * x.size(3)
     bpp = sum((torch.log(l).sum() / (-math.log(2) * num_pixels)).item() for l in out["likelihoods"].values())
     return {"psnr": psnr(x, x_hat), "bpp": bpp, "encoding_time": dt / 2.0, "decoding_time": dt / 2.0}

@@ -155,6 +155,18 @@ int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int 
 /* strided 4-D copy (chunk/cat plumbing): dst[n,c,p] (+)= src[n,c,p] */
 int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int N, int C, int HW, int accum, void* stream);
 
+/* ---- zigzag block ordering of the stf6 / oj_ICM variants (compressai/models/stf6.py:654-762; fasterRCNN_ICM.py:103-293)
+ * The latent x [B,C,H,W] (batch stride x_bs) is a grid of num_slices x num_h x num_w contiguous blocks; the zigzag
+ * tensor z [B, N, C/num_slices, H/num_h, W/num_w] (contiguous, N = num_slices*num_h*num_w <= 64) lists them shell by
+ * shell.  C, H, W must divide exactly (the reference's view() needs the same).  icm_zigzag_order fills `order` with
+ * (c*num_h + h)*num_w + w per output block and returns N (order == NULL: just N; -1 on bad arguments / capacity).
+ * Each function is its own inverse's adjoint: backward of splits = reverse on the gradient, and vice versa. */
+int icm_zigzag_order(int num_slices, int num_h, int num_w, int32_t* order, int capacity);
+int icm_zigzag_splits(const float* x, int64_t x_bs, float* z, int B, int C, int H, int W, int num_slices, int num_h,
+                      int num_w, void* stream);
+int icm_zigzag_reverse(const float* z, float* x, int64_t x_bs, int B, int C, int H, int W, int num_slices, int num_h,
+                       int num_w, void* stream);
+
 /* ---- stf (Swin) pieces on NCHW tensors ------------------------------------------------------------------
  * nn.LayerNorm(C) over the channel axis per pixel (compressai/models/stf.py:136,142,209,250,372): y = (x-mean)*rstd*gamma+beta;
  * mean/rstd [N*HW] are saved for backward (may be NULL in inference) */
