@@ -150,7 +150,8 @@ int run_conv1x1(const icm_conv_args* arr, int ngroups, long long wp_off, int g_f
   const int ncb = cdiv(ncot, c.tco);
   const long long strips = (NP + 32 * c.tpx - 1) / (32 * c.tpx);
   // independent waves need >= one wave per SIMD to beat the split-K / co-resident tilings of the staged kernel
-  if (g_force_1x1 < 0 && strips * ncb * ngroups < 1024) return -1;
+  static const long long kMinWaves = getenv("ICM_1X1_MIN_WAVES") ? atoll(getenv("ICM_1X1_MIN_WAVES")) : 1024;
+  if (g_force_1x1 < 0 && strips * ncb * ngroups < kMinWaves) return -1;
   ConvDesc d;
   for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
     const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
