@@ -1038,6 +1038,73 @@ def gc_likelihood_ste(tape, y, mu, scale, noise, lik_out, yh_out, yh2_out=None, 
         tape.bw.append(bwd)
 
 
+
+# ------------------------------------------------------------------------------------------------ stf6 plumbing
+def add(tape, a, b) -> torch.Tensor:
+    """a + b of two contiguous tensors with both gradients (stf6.py:812: mu = mu + refinement)"""
+    N = a.shape[0]
+    per = a[0].numel()
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    ones = torch.ones(N, dtype=torch.float32, device=a.device)
+    check(L.lib().icm_residual_scale(ptr(a), ptr(b), ptr(ones), ptr(out), N, per, tape.st), "add")
+    if tape.need_grad:
+        def bwd():
+            g = tape.grad_of(out)
+            if g is None:
+                return
+            accumulate(tape, a, g)
+            accumulate(tape, b, g)
+        tape.bw.append(bwd)
+    return out
+
+
+def zigzag_splits(tape, x, num_slices: int, nH: int = 2, nW: int = 2) -> torch.Tensor:
+    """ZigzagSplits (stf6.py:654-714) as one permutation launch: [B,C,H,W] -> [B, ns*nH*nW, C/ns, H/nH, W/nW].
+    The per-block views z[:, n] are what the slice loop consumes: their gradients alias one zeroed buffer that the
+    backward permutes back in one launch."""
+    B, Cc, H, W = x.shape
+    if Cc % num_slices or H % nH or W % nW:
+        raise ValueError("zigzag_splits: the latent does not split into exact blocks")
+    nb = num_slices * nH * nW
+    z = new((B, nb, Cc // num_slices, H // nH, W // nW), x.device)
+    check(L.lib().icm_zigzag_splits(ptr(x), bs(x), ptr(z), B, Cc, H, W, num_slices, nH, nW, tape.st), "zigzag_splits")
+    if tape.need_grad and tape.wants(x):
+        dz = zeros(z.shape, x.device)
+        tape.bind_grad(z, dz, True)
+        for n in range(nb):
+            tape.bind_grad(z[:, n], dz[:, n], True)
+
+        def bwd():
+            tmp = new((B, Cc, H, W), x.device)
+            check(L.lib().icm_zigzag_reverse(ptr(dz), ptr(tmp), Cc * H * W, B, Cc, H, W, num_slices, nH, nW, tape.st),
+                  "zigzag_splits_bwd")
+            accumulate(tape, x, tmp)
+        tape.bw.append(bwd)
+    else:
+        tape.stop(z)
+    return z
+
+
+def zigzag_reverse(tape, z, num_slices: int, nH: int = 2, nW: int = 2) -> torch.Tensor:
+    """ZigzagReverse (stf6.py:716-762): [B, N, Cs, Hb, Wb] -> [B, Cs*ns, Hb*nH, Wb*nW]"""
+    B, nb, Cs, Hb, Wb = z.shape
+    Cc, H, W = Cs * num_slices, Hb * nH, Wb * nW
+    assert z.is_contiguous() and nb == num_slices * nH * nW
+    x = new((B, Cc, H, W), z.device)
+    check(L.lib().icm_zigzag_reverse(ptr(z), ptr(x), Cc * H * W, B, Cc, H, W, num_slices, nH, nW, tape.st), "zigzag_reverse")
+    if tape.need_grad:
+        def bwd():
+            g = tape.grad_of(x)
+            if g is None:
+                return
+            tmp = new(z.shape, z.device)
+            check(L.lib().icm_zigzag_splits(ptr(g), bs(g), ptr(tmp), B, Cc, H, W, num_slices, nH, nW, tape.st),
+                  "zigzag_reverse_bwd")
+            accumulate(tape, z, tmp)
+        tape.bw.append(bwd)
+    return x
+
 # ------------------------------------------------------------------------------------------------ autograd bridge
 class _TapeFn(torch.autograd.Function):
     @staticmethod

@@ -467,6 +467,121 @@ def stf_synthesis(tape: E.Tape, P, Y_hat, drops=None, window: int = 4):
     return E.conv2d(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
 
 
+
+# ------------------------------------------------------------------------------------------------ stf6 (zigzag + Swin-refined means)
+STF6_SLICES, STF6_NUMBER, STF6_SUPPORT, STF6_MU_HEADS = 6, 2, 16, 4
+
+
+def stf6_drop_path_rates(drop_path_rate: float = 0.2, depths=STF_DEPTHS, nblocks: int = STF6_SLICES * 4) -> Dict[str, float]:
+    """stf's rates plus the refinement stacks (stf6.py:469-484: built after ``depths = depths[::-1]``)"""
+    out = stf_drop_path_rates(drop_path_rate, depths)
+    dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+    for b in range(nblocks):
+        o = 0
+        for i, d in enumerate(depths[::-1]):
+            for j in range(d):
+                out[f"mu_Swin.{b}.{i}.blocks.{j}"] = dpr[o + j]
+            o += d
+    return out
+
+
+def hyper_slices_zigzag(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, drops,
+                        num_slices: int = STF6_SLICES, max_support: int = STF6_SUPPORT, window: int = 4,
+                        keep: Optional[dict] = None, bucket_marks: Optional[dict] = None):
+    """Hyperprior + zigzag slice loop of SymmetricalTransFormer3.forward (stf6.py:778-858) ->
+    (y_hat [B,M,h,w], y_likelihoods [B, nb*M/ns, h/2, w/2] in zigzag block order, z_likelihoods).
+    The latent, its means and scales are cut into nb = ns*2*2 blocks by one permutation launch each; block i is coded
+    from cat[means_i, y_hat of the previous min(i, max_support) blocks]: the y_hat blocks live in ONE buffer in coding
+    order, so that support is a contiguous channel range copied behind the block's own means; the mean is refined by
+    four Swin BasicLayers on the block map (mu_Swin[i]) before the likelihood; ZigzagReverse assembles y_hat.
+    noise_y: None or [B, nb, M/ns, h/2, w/2] (zigzag order)."""
+    dev, N, M, h, w = y.device, y.shape[0], y.shape[1], y.shape[2], y.shape[3]
+    need = tape.need_grad
+    nH = nW = STF6_NUMBER
+    nb, cs, hb, wb = num_slices * nH * nW, M // num_slices, h // nH, w // nW
+    if M % num_slices or h % nH or w % nW or hb % window or wb % window:
+        raise ValueError("stf6: the latent must split into 2 x 2 blocks that are multiples of the window (input % 128 == 0)")
+    if bucket_marks is not None:
+        bucket_marks[2] = len(tape.bw)
+    z = _chain(tape, P, "h_a", VT(y), strides=(1, 1, 2, 1, 2))
+    _, z_lik = E.eb_likelihood(tape, z, P, "entropy_bottleneck", noise_z)
+    z_hat = E.ste_round_medians(tape, z, P["entropy_bottleneck.quantiles"])
+    lat_scales, lat_means = E.new((N, M, h, w), dev), E.new((N, M, h, w), dev)
+    _h_s_pair(tape, P, "h_scale_s", "h_mean_s", z_hat, lat_scales, lat_means)
+    y_zz = E.zigzag_splits(tape, y, num_slices, nH, nW)
+    sc_zz = E.zigzag_splits(tape, lat_scales, num_slices, nH, nW)
+    mu_zz = E.zigzag_splits(tape, lat_means, num_slices, nH, nW)
+    YH = E.new((N, nb, cs, hb, wb), dev)          # y_hat blocks in coding order
+    YHc = YH.view(N, nb * cs, hb, wb)
+    Y_lik = E.new((N, nb, cs, hb, wb), dev)
+    if need:
+        dYH = E.zeros(YH.shape, dev)
+        dYHc = dYH.view(N, nb * cs, hb, wb)
+        tape.bind_grad(YH, dYH, True)
+        for i in range(nb):
+            tape.bind_grad(YH[:, i], dYH[:, i], True)
+            k = min(i, max_support)
+            if k > 1:
+                tape.bind_grad(YHc[:, cs * (i - k):cs * i], dYHc[:, cs * (i - k):cs * i], True)
+    if bucket_marks is not None:
+        bucket_marks[1] = len(tape.bw)
+    mus, scs = [], []
+    rdepths = STF_DEPTHS[::-1]
+    for i in range(nb):
+        k = min(i, max_support)
+        MSi, SSi = E.new((N, cs * (1 + k), hb, wb), dev), E.new((N, cs * (1 + k), hb, wb), dev)
+        LSi = E.new((N, cs * (2 + k), hb, wb), dev)
+        yh_pre = LSi[:, cs * (1 + k):]
+        if need:
+            for buf in (MSi, SSi, LSi):
+                d = E.zeros(buf.shape, dev)
+                tape.bind_grad(buf, d, True)
+                tape.bind_grad(buf[:, :cs], d[:, :cs], True)
+                if k > 0:
+                    tape.bind_grad(buf[:, cs:cs * (1 + k)], d[:, cs:cs * (1 + k)], True)
+                if buf is LSi:
+                    tape.bind_grad(buf[:, :cs * (1 + k)], d[:, :cs * (1 + k)], True)
+                    tape.bind_grad(yh_pre, d[:, cs * (1 + k):], True)
+        _copy_op(tape, mu_zz[:, i], MSi[:, :cs])
+        _copy_op(tape, sc_zz[:, i], SSi[:, :cs])
+        if k > 0:
+            sup = YHc[:, cs * (i - k):cs * i]
+            _copy_op(tape, sup, MSi[:, cs:])
+            _copy_op(tape, sup, SSi[:, cs:])
+        mu, sc = _chain_pair(tape, P, f"cc_mean_transforms2.{i}", f"cc_scale_transforms2.{i}", VT(MSi), VT(SSi))
+        t = mu
+        for l in range(4):
+            t = _basic_layer(tape, P, f"mu_Swin.{i}.{l}", t, rdepths[l], STF6_MU_HEADS, window, None, drops)
+        mu = E.add(tape, mu, t)
+        E.gc_likelihood_ste(tape, y_zz[:, i], mu, sc, None if noise_y is None else noise_y[:, i], Y_lik[:, i], yh_pre)
+        _copy_op(tape, MSi, LSi[:, :cs * (1 + k)])
+        _chain(tape, P, f"lrp_transforms2.{i}", VT(LSi), out=YH[:, i], lrp_aux=yh_pre)
+        if keep is not None:
+            mus.append(mu)
+            scs.append(sc)
+    if bucket_marks is not None:
+        bucket_marks[0] = len(tape.bw)
+    Y_hat = E.zigzag_reverse(tape, YH, num_slices, nH, nW)
+    Y_lik4 = Y_lik.view(N, nb * cs, hb, wb)
+    if keep is not None:
+        keep.update(y=y, z=z, z_hat=z_hat, y_hat=Y_hat, y_zz=y_zz, mu=torch.stack(mus, 1), scale=torch.stack(scs, 1))
+    return Y_hat, Y_lik4, z_lik
+
+
+def stf6_forward(tape: E.Tape, P: Dict[str, torch.Tensor], x: torch.Tensor, noise_z=None, noise_y=None,
+                 drops: Optional[Dict[str, torch.Tensor]] = None, window: int = 4, keep: Optional[dict] = None,
+                 bucket_marks: Optional[dict] = None):
+    """SymmetricalTransFormer3.forward (models/stf6.py:764-872) on the HIP engine: stf's analysis / synthesis stacks
+    around the zigzag slice loop."""
+    y = stf_analysis(tape, P, x, drops, window)
+    Y_hat, Y_lik, z_lik = hyper_slices_zigzag(tape, P, y, noise_z, noise_y, drops, window=window, keep=keep,
+                                              bucket_marks=bucket_marks)
+    x_hat = stf_synthesis(tape, P, Y_hat, drops, window)
+    if tape.need_grad:
+        _split_lik(tape, Y_lik, STF6_SLICES * 4)
+    return x_hat, Y_lik, z_lik
+
+
 def _pad_eval_input(x, training: bool):
     """Inputs whose sides are not multiples of 64 (six stride-2 stages).  The reference pads feature maps inside its
     Swin blocks (stf.py:158-163) and crops the slice-chain outputs (cnn.py:165,169), but its own evaluation entry
@@ -855,3 +970,100 @@ class SymmetricalTransFormer(CompressionModel):
         x_hat = stf_synthesis(tape, P, y_hat, None, self.window_size)
         L.check(L.lib().icm_clamp(L.ptr(x_hat), x_hat.numel(), 0.0, 1.0, tape.st), "clamp")
         return {"x_hat": x_hat}
+
+
+class SymmetricalTransFormer3(SymmetricalTransFormer):
+    """``stf6`` of the reference's zoo (models/stf6.py:384-872): the stf analysis / synthesis transforms around a
+    zigzag-ordered entropy model -- the latent is coded as 24 blocks (6 channel groups x 2 x 2 spatial halves,
+    ``ZigzagSplits``), every block's mean is refined by a four-layer Swin stack (``mu_Swin``), up to 16 previous
+    blocks condition the next.  Same module names and state-dict as the reference (``sigma_Swin`` / ``LRP_Swin`` are
+    registered but unused by ``forward``, as there); inputs must be multiples of 128 (block maps are multiples of the
+    4 x 4 window).  ``compress`` / ``decompress`` are not mirrored for this variant."""
+
+    def __init__(self, pretrain_img_size=256, patch_size=2, in_chans=3, embed_dim=48, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=4, num_slices=6, Mask_win_size=8, num_sliding=4, mlp_ratio=4.,
+                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2,
+                 norm_layer=nn.LayerNorm, patch_norm=True, frozen_stages=-1, use_checkpoint=False):
+        if num_slices != 6:
+            raise NotImplementedError("icm SymmetricalTransFormer3: only the reference's default architecture")
+        super().__init__(pretrain_img_size, patch_size, in_chans, embed_dim, depths, num_heads, window_size, 12,
+                         mlp_ratio, qkv_bias, qk_scale, drop_rate, attn_drop_rate, drop_path_rate, norm_layer, patch_norm,
+                         frozen_stages, use_checkpoint)
+        # re-register everything after syn_layers in the reference's order (stf6.py:465-621)
+        tail = {}
+        for name in ("end_conv", "h_a", "h_mean_s", "h_scale_s", "entropy_bottleneck", "gaussian_conditional"):
+            tail[name] = getattr(self, name)
+            delattr(self, name)
+        for name in ("cc_mean_transforms", "cc_scale_transforms", "lrp_transforms"):
+            delattr(self, name)
+        self.num_slices = num_slices
+        self.max_support_slices = STF6_SUPPORT
+        self.Mask_win_size = Mask_win_size
+        cs = 384 // num_slices
+        rdepths = list(depths)[::-1]
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+
+        def refine_stacks(n):
+            return nn.ModuleList(nn.ModuleList(BasicLayer(
+                dim=cs, depth=rdepths[i], num_heads=STF6_MU_HEADS, window_size=window_size, mlp_ratio=mlp_ratio,
+                qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(rdepths[:i]):sum(rdepths[:i + 1])], norm_layer=norm_layer, downsample=None,
+                inverse=True) for i in range(self.num_layers)) for _ in range(n))
+        self.mu_Swin = refine_stacks(num_slices * 4)
+        self.sigma_Swin = refine_stacks(num_slices)
+        self.LRP_Swin = refine_stacks(num_slices)
+        for name in ("end_conv", "h_a", "h_mean_s", "h_scale_s"):
+            setattr(self, name, tail[name])
+
+        def cc(extra):
+            return nn.ModuleList(nn.Sequential(
+                conv(cs + cs * min(i + extra, STF6_SUPPORT + extra), 224, stride=1, kernel_size=3), nn.GELU(),
+                conv(224, 176, stride=1, kernel_size=3), nn.GELU(),
+                conv(176, 128, stride=1, kernel_size=3), nn.GELU(),
+                conv(128, 64, stride=1, kernel_size=3), nn.GELU(),
+                conv(64, cs, stride=1, kernel_size=3)) for i in range(num_slices * 4))
+        self.cc_mean_transforms2 = cc(0)
+        self.cc_scale_transforms2 = cc(0)
+        self.lrp_transforms2 = cc(1)
+        self.entropy_bottleneck = tail["entropy_bottleneck"]
+        self.gaussian_conditional = tail["gaussian_conditional"]
+
+    def draw_drops(self, B: int, device, generator=None) -> Dict[str, torch.Tensor]:
+        out = {}
+        for k, r in stf6_drop_path_rates(self.drop_path_rate).items():
+            d = _draw_drop(r, B, device, generator)
+            if d is not None:
+                out[k] = d
+        return out
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("SymmetricalTransFormer3.forward expects [B,3,H,W]")
+        if x.shape[2] % 128 or x.shape[3] % 128:
+            raise ValueError("SymmetricalTransFormer3: image sides must be multiples of 128 (2 x 2 zigzag blocks of "
+                             "4 x 4-window Swin maps at 1/16 resolution)")
+        names, params = _named(self)
+        dev = x.device
+        nz = ny = drops = None
+        if self.training:
+            nz, ny = _train_noise(self._noise, x, 192, 384)
+            B, hb, wb = x.shape[0], x.shape[2] // 32, x.shape[3] // 32
+            ny = ny.reshape(B, 24, 64, hb, wb) if ny.dim() == 4 else ny.contiguous()   # iid noise: any layout is the same draw
+            drops = self._drops if self._drops is not None else self.draw_drops(B, dev)
+            drops = {k: v.to(dev, torch.float32).contiguous() for k, v in drops.items()}
+        ws = self.window_size
+
+        def runner(tape, xin, *ps):
+            return stf6_forward(tape, dict(zip(names, ps)), xin, nz, ny, drops, ws)
+
+        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
+        return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
+
+    def update(self, scale_table=None, force=False):
+        return self._update_tables(scale_table, force)
+
+    def compress(self, x, _debug=None):
+        raise NotImplementedError("stf6: the zigzag entropy coder loop (stf6.py:898-1057) is not mirrored")
+
+    def decompress(self, strings, shape):
+        raise NotImplementedError("stf6: the zigzag entropy coder loop (stf6.py:898-1057) is not mirrored")

@@ -24,11 +24,13 @@ import torch.distributed as dist
 from . import _lib as L
 from . import engine as E
 from ._lib import check, ptr
-from .models import SymmetricalTransFormer, stf_forward, wacnn_forward
+from .models import SymmetricalTransFormer, SymmetricalTransFormer3, stf6_forward, stf_forward, wacnn_forward
 
 # bucket -> parameter-name prefixes, in the order their gradients complete during backward
 # (synthesis transform | slice chains | hyper path | analysis transform); names of the cnn and the stf model
-BUCKETS = [("g_s", "syn_layers", "end_conv"), ("cc_mean_transforms", "cc_scale_transforms", "lrp_transforms"),
+BUCKETS = [("g_s", "syn_layers", "end_conv"),
+           ("cc_mean_transforms", "cc_scale_transforms", "lrp_transforms", "cc_mean_transforms2", "cc_scale_transforms2",
+            "lrp_transforms2", "mu_Swin", "sigma_Swin", "LRP_Swin"),
            ("h_a", "h_mean_s", "h_scale_s", "entropy_bottleneck"), ("g_a", "patch_embed", "layers")]
 
 
@@ -168,6 +170,7 @@ class Trainer:
         self._pack_seq = None     # weight-packing miss sequence of the first step (windowed batch packing afterwards)
         self.pack_window = int(_os.environ.get("ICM_PACK_WINDOW", "24"))
         self.is_stf = isinstance(model, SymmetricalTransFormer)
+        self.is_stf6 = isinstance(model, SymmetricalTransFormer3)
         self.lat_ch = 384 if self.is_stf else 320
 
     def params(self) -> Dict[str, torch.Tensor]:
@@ -247,7 +250,11 @@ class Trainer:
             if drops is None:   # stochastic depth, drawn per step like timm's DropPath (stf.py:145)
                 drops = self.model.draw_drops(B, dev, generator=self.gen)
             drops = {k: v.to(dev, torch.float32).contiguous() for k, v in drops.items()}
-            x_hat, y_lik, z_lik = stf_forward(tape, P, x, nz, ny, drops, bucket_marks=marks)
+            if self.is_stf6:   # zigzag blocks: iid noise, so any layout of the same draw is the same distribution
+                ny6 = ny if ny.dim() == 5 else ny.reshape(B, 24, 64, H // 32, W // 32)
+                x_hat, y_lik, z_lik = stf6_forward(tape, P, x, nz, ny6, drops, bucket_marks=marks)
+            else:
+                x_hat, y_lik, z_lik = stf_forward(tape, P, x, nz, ny, drops, bucket_marks=marks)
         else:
             x_hat, y_lik, z_lik = wacnn_forward(tape, P, x, nz, ny, bucket_marks=marks)
         # ---- R-D loss forward + seeds (train.py:53-76)

@@ -305,3 +305,55 @@ for _i in range(12):
 
 def make_stf_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
     return _make(stf_spec(), STF_GAINS, salt)
+
+
+# ----------------------------------------------------------------------------- stf6 (SymmetricalTransFormer3)
+STF6_SLICES = 6            # stf6.py:393 num_slices -> 6 * 2 * 2 = 24 zigzag blocks of 64 channels
+STF6_BLOCKS = 24
+STF6_SUPPORT = 16          # stf6.py:414 max_support_slices
+
+
+def stf6_spec(embed: int = 48) -> "OrderedDict[str, tuple]":
+    """Ordered key -> shape of SymmetricalTransFormer3.state_dict() (compressai/models/stf6.py:384-622): the stf
+    analysis / synthesis stacks, 24 + 6 + 6 four-layer Swin refinement stacks on 64-channel block maps (mu_Swin is the
+    only one forward() uses, :806-810; sigma_Swin / LRP_Swin are registered but idle), the hyper path of stf and 24
+    cc / lrp chains whose first layer sees 64 * (1 + min(i, 16)) (+ 64 for lrp) channels (:565-604)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    depths, heads = (2, 2, 6, 2), (3, 6, 12, 24)
+    base = stf_spec(embed)
+    for k, v in base.items():            # patch_embed, layers, syn_layers come first, in stf's order
+        if k.startswith(("patch_embed.", "layers.", "syn_layers.")):
+            s[k] = v
+    cs = 384 // STF6_SLICES
+    rdepths = depths[::-1]
+    for fam, n in (("mu_Swin", STF6_BLOCKS), ("sigma_Swin", STF6_SLICES), ("LRP_Swin", STF6_SLICES)):
+        for b in range(n):
+            for i in range(4):
+                for j in range(rdepths[i]):
+                    _swin_spec(s, f"{fam}.{b}.{i}.blocks.{j}", cs, 4)
+    for k, v in base.items():
+        if k.startswith(("end_conv.", "h_a.", "h_mean_s.", "h_scale_s.")):
+            s[k] = v
+    chain = (224, 176, 128, 64, cs)
+    for fam, extra in (("cc_mean_transforms2", 0), ("cc_scale_transforms2", 0), ("lrp_transforms2", 1)):
+        for i in range(STF6_BLOCKS):
+            ci = cs + cs * min(i + extra, STF6_SUPPORT + extra)
+            for j, co in zip((0, 2, 4, 6, 8), chain):
+                _conv_spec(s, f"{fam}.{i}.{j}", co, ci, 3)
+                ci = co
+    for k, v in base.items():
+        if k.startswith(("entropy_bottleneck.", "gaussian_conditional.")):
+            s[k] = v
+    return s
+
+
+STF6_GAINS = {"layers.3.blocks.1.mlp.fc2.weight": 6.0, "h_a.8.weight": 80.0}
+for _i in range(STF6_BLOCKS):
+    STF6_GAINS[f"cc_scale_transforms2.{_i}.8.weight"] = 12.0
+    STF6_GAINS[f"cc_mean_transforms2.{_i}.8.weight"] = 8.0
+    STF6_GAINS[f"lrp_transforms2.{_i}.8.weight"] = 8.0
+    STF6_GAINS[f"mu_Swin.{_i}.3.blocks.1.mlp.fc2.weight"] = 4.0    # the refinement must visibly move mu
+
+
+def make_stf6_state_dict(salt: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return _make(stf6_spec(), STF6_GAINS, salt)
