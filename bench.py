@@ -153,8 +153,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shape-table", action="store_true")
     ap.add_argument("--fwd-only", action="store_true", help="time eval-mode forward only (reported separately)")
-    ap.add_argument("--model", default="cnn", choices=["cnn", "stf"], help="cnn = BASELINE.json headline (default); "
-                    "stf = configs[3], reported as an extra line")
+    ap.add_argument("--model", default="cnn", choices=["cnn", "stf", "stf6"], help="cnn = BASELINE.json headline (default); "
+                    "stf = configs[3], stf6 = the zigzag variant (SURVEY 8 f3): reported as extra lines")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
@@ -190,9 +190,9 @@ def main():
     def one():
         if args.fwd_only:
             from icm_amd import engine as E
-            from icm_amd.models import stf_forward, wacnn_forward
-            (stf_forward if args.model == "stf" else wacnn_forward)(E.Tape(need_grad=False, packed_cache=packed),
-                                                                    tr.params(), x)
+            from icm_amd.models import stf6_forward, stf_forward, wacnn_forward
+            {"cnn": wacnn_forward, "stf": stf_forward, "stf6": stf6_forward}[args.model](
+                E.Tape(need_grad=False, packed_cache=packed), tr.params(), x)
             return None
         return tr.step(x)
 
@@ -233,13 +233,18 @@ def main():
         gflop = FWD_GFLOP_PER_IMG if args.fwd_only else STEP_GFLOP_PER_IMG
         if args.model == "stf":   # stf forward 33.498 GMAC = 67.0 GFLOP/image
             gflop = 67.0 if args.fwd_only else 3 * 67.0
+        if args.model == "stf6":  # no survey figure: algorithmic FLOP of the GEMM / attention launches of the profiled step
+            gflop = (sum(v["gflop"] for v in fams.values()) / BATCH_PER_GPU) if fams else float("nan")
         line = {
-            "metric": ("images/sec (256x256) cnn-hyperprior (WACNN) " if args.model == "cnn" else
-                       "images/sec (256x256) stf (SymmetricalTransFormer) ") + ("forward" if args.fwd_only else "training step"),
+            "metric": {"cnn": "images/sec (256x256) cnn-hyperprior (WACNN) ",
+                       "stf": "images/sec (256x256) stf (SymmetricalTransFormer) ",
+                       "stf6": "images/sec (256x256) stf6 (SymmetricalTransFormer3, zigzag) "}[args.model] +
+                      ("forward" if args.fwd_only else "training step"),
             "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (("cnn (WACNN N=192 M=320)" if args.model == "cnn" else "stf (Swin, embed 48, 12 slices)") +
+            "config": {"workload": ({"cnn": "cnn (WACNN N=192 M=320)", "stf": "stf (Swin, embed 48, 12 slices)",
+                                     "stf6": "stf6 (Swin, embed 48, 24 zigzag blocks, mu_Swin refinement)"}[args.model] +
                                     (" train step, lambda=0.0067 MSE, batch 16/GPU synthetic 256x256, Adam lr 1e-4 + "
                                      "aux Adam, clip 1.0" if not args.fwd_only else
                                      " eval forward, batch 16/GPU synthetic 256x256")),
