@@ -73,6 +73,10 @@ __device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& 
       v[q] = acc[half * 8 + q] + bv[q];
       if constexpr (EPI == ICM_EPI_RES) v[q] += rv[q];
       if constexpr (EPI == ICM_EPI_RES_GELU) v[q] += gelu_f(rv[q]);
+      if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
+        // materialised activation for the consumers of this pre-activation (forward only): y2 = gelu(y)
+        if (y2b && ok[q]) y2b[off[q]] = gelu_f(v[q]);
+      }
       if constexpr (EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN) {
         if (y2b && ok[q]) y2b[off[q]] = v[q];
         v[q] = av[q] * (EPI == ICM_EPI_GDN ? rsqrtf(v[q]) : sqrtf(v[q]));

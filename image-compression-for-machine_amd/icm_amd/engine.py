@@ -87,6 +87,23 @@ def _key(t: torch.Tensor):
     return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
 
 
+# Materialised activations.  Pre-activations stay the stored tensors (the backward needs them for gelu'), but a
+# producer called with act_out=True also stores gelu(y) from its epilogue; consumers of VT(y, ACT_GELU) -- the next
+# convolution's operand, its weight gradient's operand, a residual add -- then read that tensor with NO activation:
+# GELU is evaluated once per element instead of once per consumer (x co-blocks), and activation-free operands are
+# eligible for the LDS-DMA staging of the weight-gradient loaders.  ICM_MATERIALIZE=0 keeps everything virtual.
+_MATERIALIZE = _os.environ.get("ICM_MATERIALIZE", "1") != "0"
+
+
+def _operand(tape, xv: "VT"):
+    """(tensor, activation) a kernel should read for the virtual tensor xv"""
+    if xv.act == ACT_GELU and _MATERIALIZE:
+        m = tape.mat.get(_key(xv.t))
+        if m is not None:
+            return m, ACT_NONE
+    return xv.t, xv.act
+
+
 class Tape:
     def __init__(self, need_grad: bool = True, packed_cache: Optional[dict] = None):
         """packed_cache: a dict kept by the caller across forward calls with CONSTANT weights (inference): the packed
@@ -112,6 +129,7 @@ class Tape:
         self.progress_every = 0
         self.min_jobs = 8
         self._pending_res: Dict[tuple, tuple] = {}   # key(t) -> (t, dy, gelu): identity-path gradient not yet added
+        self.mat: Dict[tuple, torch.Tensor] = {}   # key(pre-activation t) -> gelu(t) stored by t's producer (act_out)
         self.hold_wgrads = False  # True: queue weight gradients without periodic flushes (the slice-chain section
         #                           batches its 150 small problems by geometry at the section end)
         self.st = L.stream()
@@ -395,12 +413,14 @@ def copy_into(tape, src, dst, accum=0):
 
 # ------------------------------------------------------------------------------------------------ conv family
 def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, output_padding=0, res: Optional[VT] = None,
-           out=None, pixel_shuffle=0, lrp_aux=None, w_as: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+           out=None, pixel_shuffle=0, lrp_aux=None, w_as: Optional[Tuple[int, int]] = None,
+           act_out: bool = False) -> torch.Tensor:
     """nn.Conv2d / nn.ConvTranspose2d / nn.Linear(on NCHW) forward with fused neighbours.  Returns the
     pre-activation output tensor (or y_hat for the LRP epilogue).  w_as=(d0, d1): use the (contiguous) weight as a
     [d0, d1, 1, 1] matrix (thin-channel layers run as 1x1 GEMMs over (channel, tap) pairs); gradients still land in
-    the weight's own buffer."""
+    the weight's own buffer.  act_out: the consumers of the result apply GELU -- store gelu(y) next to y (tape.mat)."""
     x, act = xv.t, xv.act
+    xf, actf = _operand(tape, xv)       # what the forward kernel and the weight gradient read
     N, Cin, H, W = x.shape
     w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
     if w_as is not None:
@@ -424,15 +444,18 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
     assert tuple(y.shape) == oshape, (tuple(y.shape), oshape)
     epi, resv, aux, y2 = EPI_NONE, None, None, None
     if res is not None:
-        epi = EPI_RES_GELU if res.act == ACT_GELU else EPI_RES
         assert res.act in (ACT_NONE, ACT_GELU)
-        resv = res.t
+        resv, ract = _operand(tape, res)
+        epi = EPI_RES_GELU if ract == ACT_GELU else EPI_RES
     if lrp_aux is not None:
         assert res is None
         epi, aux = EPI_LRP, lrp_aux
         y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    conv_launch(tape, x, wp, b, y, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, transposed=transposed,
-                OH=OH, OW=OW, pro_act=act, epi=epi, res=resv, aux=aux, y2=y2, ps=pixel_shuffle)
+    elif act_out and _MATERIALIZE:
+        y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        tape.mat[_key(y)] = y2
+    conv_launch(tape, xf, wp, b, y, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, transposed=transposed,
+                OH=OH, OW=OW, pro_act=actf, epi=epi, res=resv, aux=aux, y2=y2, ps=pixel_shuffle)
     if not tape.need_grad:
         return y
 
@@ -462,10 +485,10 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             gw, acc = tape.grad_for_write(w)
             if not transposed:
                 gb_, accb = tape.grad_for_write(b) if fuse_b else (None, 0)
-                wgrad_defer(tape, dy, x, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=act,
+                wgrad_defer(tape, dy, xf, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=actf,
                             accum=acc, dbias=gb_, accum_bias=accb)
             else:
-                wgrad_defer(tape, x, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=act,
+                wgrad_defer(tape, xf, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=actf,
                             accum=acc)
         if tape.wants(x):
             rg = tape.take_res_grad(x, act == ACT_GELU) if act in (ACT_GELU, ACT_NONE) else None
@@ -579,7 +602,8 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
 MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_igemm.hip
 
 
-def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, ress=None, pixel_shuffle=0):
+def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, ress=None, pixel_shuffle=0,
+                 act_out: bool = False):
     """The same stride-1 convolution shape applied to several independent (input, weight) pairs in ONE launch:
     cc_mean_transforms[i] || cc_scale_transforms[i] (cnn.py:164-168), and -- because the support of slice i is
     y_hat_slices[:max_support] (cnn.py:161), i.e. the FIRST five slices -- all chains of the slices >= max_support at
@@ -604,13 +628,28 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
     assert not (pixel_shuffle and (lrp or ress is not None))
     y2s = [new((N, Cout, OH, OW), x0.device) for _ in range(n)] if lrp else None
     epi = EPI_LRP if lrp else EPI_NONE
+    # materialised operands: used only when EVERY member has one (a launch has one activation flag)
+    ops = [_operand(tape, v) for v in xvs]
+    if all(a == ACT_NONE for _, a in ops):
+        xfs, actf = [t for t, _ in ops], ACT_NONE
+    else:
+        xfs, actf = [v.t for v in xvs], act
+    resf = None
     if ress is not None:
         assert not lrp and all(r.act == ress[0].act for r in ress) and ress[0].act in (ACT_NONE, ACT_GELU)
-        epi = EPI_RES_GELU if ress[0].act == ACT_GELU else EPI_RES
-    conv_launch_grouped(tape, [v.t for v in xvs], wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
-                        transposed=0, OH=OH, OW=OW, pro_act=act, epi=epi,
+        rops = [_operand(tape, r) for r in ress]
+        if all(a == ACT_NONE for _, a in rops):
+            resf, epi = [t for t, _ in rops], EPI_RES
+        else:
+            resf, epi = [r.t for r in ress], (EPI_RES_GELU if ress[0].act == ACT_GELU else EPI_RES)
+    if act_out and _MATERIALIZE and not lrp:
+        y2s = [new(oshape, x0.device) for _ in range(n)]
+        for y, y2 in zip(ys, y2s):
+            tape.mat[_key(y)] = y2
+    conv_launch_grouped(tape, xfs, wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
+                        transposed=0, OH=OH, OW=OW, pro_act=actf, epi=epi,
                         auxs=list(lrp_auxs) if lrp else None, y2s=y2s,
-                        ress=[r.t for r in ress] if ress is not None else None, ps=pixel_shuffle)
+                        ress=resf, ps=pixel_shuffle)
     if not tape.need_grad:
         return ys
 
@@ -638,10 +677,10 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
         if ress is not None:
             for r, dy in zip(ress, dys):
                 tape.defer_res_grad(r.t, dy, r.act == ACT_GELU)
-        for v, w, b, dy in zip(xvs, ws, bs_, dys):
+        for xf_, w, b, dy in zip(xfs, ws, bs_, dys):
             gw, acc = tape.grad_for_write(w)
             gb_, accb = tape.grad_for_write(b)
-            wgrad_defer(tape, dy, v.t, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=1, pad=pad, act_b=act, accum=acc,
+            wgrad_defer(tape, dy, xf_, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=1, pad=pad, act_b=actf, accum=acc,
                         dbias=gb_, accum_bias=accb)
         # input gradients: one grouped dgrad.  Members that share an input tensor (the fixed support of the late
         # slices) write private buffers which are then summed into the shared gradient; distinct inputs are
@@ -733,9 +772,9 @@ def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> to
 # ------------------------------------------------------------------------------------------------ attention gate
 def residual_unit(tape, xv: VT, P, p) -> VT:
     """layers/layers.py:52-72 with virtual GELUs: returns VT(pre, GELU)."""
-    u1 = conv2d(tape, xv, P[p + ".conv.0.weight"], P[p + ".conv.0.bias"])
-    u2 = conv2d(tape, VT(u1, ACT_GELU), P[p + ".conv.2.weight"], P[p + ".conv.2.bias"], pad=1)
-    u3 = conv2d(tape, VT(u2, ACT_GELU), P[p + ".conv.4.weight"], P[p + ".conv.4.bias"], res=xv)
+    u1 = conv2d(tape, xv, P[p + ".conv.0.weight"], P[p + ".conv.0.bias"], act_out=True)
+    u2 = conv2d(tape, VT(u1, ACT_GELU), P[p + ".conv.2.weight"], P[p + ".conv.2.bias"], pad=1, act_out=True)
+    u3 = conv2d(tape, VT(u2, ACT_GELU), P[p + ".conv.4.weight"], P[p + ".conv.4.bias"], res=xv, act_out=True)
     return VT(u3, ACT_GELU)
 
 
@@ -743,13 +782,13 @@ def residual_unit_pair(tape, xa: VT, xb: VT, P, pa, pb):
     """the same ResidualUnit step of the two independent gate branches (conv_a[j], conv_b[j+1]; layers.py:75-81) as
     grouped launches: the 4 096-pixel gates (dim 320) fill only half the chip one branch at a time"""
     u1 = conv2d_group(tape, [xa, xb], [P[pa + ".conv.0.weight"], P[pb + ".conv.0.weight"]],
-                      [P[pa + ".conv.0.bias"], P[pb + ".conv.0.bias"]], pad=0)
+                      [P[pa + ".conv.0.bias"], P[pb + ".conv.0.bias"]], pad=0, act_out=True)
     u2 = conv2d_group(tape, [VT(u1[0], ACT_GELU), VT(u1[1], ACT_GELU)],
                       [P[pa + ".conv.2.weight"], P[pb + ".conv.2.weight"]],
-                      [P[pa + ".conv.2.bias"], P[pb + ".conv.2.bias"]], pad=1)
+                      [P[pa + ".conv.2.bias"], P[pb + ".conv.2.bias"]], pad=1, act_out=True)
     u3 = conv2d_group(tape, [VT(u2[0], ACT_GELU), VT(u2[1], ACT_GELU)],
                       [P[pa + ".conv.4.weight"], P[pb + ".conv.4.weight"]],
-                      [P[pa + ".conv.4.bias"], P[pb + ".conv.4.bias"]], pad=0, ress=[xa, xb])
+                      [P[pa + ".conv.4.bias"], P[pb + ".conv.4.bias"]], pad=0, ress=[xa, xb], act_out=True)
     return VT(u3[0], ACT_GELU), VT(u3[1], ACT_GELU)
 
 
@@ -864,7 +903,7 @@ def swin_block(tape, x, P, p, heads, ws, shift, dp=None) -> torch.Tensor:
         a = conv2d(tape, VT(o), P[p + ".attn.proj.weight"], P[p + ".attn.proj.bias"])
         x1 = residual_scale(tape, x, a, dp[0])
     n2 = layernorm(tape, x1, P[p + ".norm2.weight"], P[p + ".norm2.bias"])
-    hdn = conv2d(tape, VT(n2), P[p + ".mlp.fc1.weight"], P[p + ".mlp.fc1.bias"])
+    hdn = conv2d(tape, VT(n2), P[p + ".mlp.fc1.weight"], P[p + ".mlp.fc1.bias"], act_out=True)
     if dp is None:
         return conv2d(tape, VT(hdn, ACT_GELU), P[p + ".mlp.fc2.weight"], P[p + ".mlp.fc2.bias"], res=VT(x1))
     m = conv2d(tape, VT(hdn, ACT_GELU), P[p + ".mlp.fc2.weight"], P[p + ".mlp.fc2.bias"])

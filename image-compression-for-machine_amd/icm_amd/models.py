@@ -108,7 +108,7 @@ def _chain(tape, P, p, xv: VT, strides=(1, 1, 1, 1, 1), out=None, lrp_aux=None):
     for j, i in enumerate((0, 2, 4, 6, 8)):
         last = j == 4
         t = E.conv2d(tape, xv, P[f"{p}.{i}.weight"], P[f"{p}.{i}.bias"], stride=strides[j], pad=1,
-                     out=out if last else None, lrp_aux=lrp_aux if last else None)
+                     out=out if last else None, lrp_aux=lrp_aux if last else None, act_out=not last)
         xv = VT(t, ACT_GELU)
     return t
 
@@ -118,17 +118,17 @@ def _chain_pair(tape, P, p1, p2, xv1: VT, xv2: VT):
     their five convolutions as one grouped launch (forward and dgrad)."""
     for i in (0, 2, 4, 6, 8):
         t1, t2 = E.conv2d_group(tape, [xv1, xv2], [P[f"{p1}.{i}.weight"], P[f"{p2}.{i}.weight"]],
-                                [P[f"{p1}.{i}.bias"], P[f"{p2}.{i}.bias"]], pad=1)
+                                [P[f"{p1}.{i}.bias"], P[f"{p2}.{i}.bias"]], pad=1, act_out=i != 8)
         xv1, xv2 = VT(t1, ACT_GELU), VT(t2, ACT_GELU)
     return t1, t2
 
 
 def _h_s(tape, P, p, z_hat, out):
     """h_mean_s / h_scale_s (cnn.py:66-88): PixelShuffle fused into the subpel convs' stores."""
-    u = E.conv2d(tape, VT(z_hat), P[p + ".0.weight"], P[p + ".0.bias"], pad=1)
-    u = E.conv2d(tape, VT(u, ACT_GELU), P[p + ".2.0.weight"], P[p + ".2.0.bias"], pad=1, pixel_shuffle=2)
-    u = E.conv2d(tape, VT(u, ACT_GELU), P[p + ".4.weight"], P[p + ".4.bias"], pad=1)
-    u = E.conv2d(tape, VT(u, ACT_GELU), P[p + ".6.0.weight"], P[p + ".6.0.bias"], pad=1, pixel_shuffle=2)
+    u = E.conv2d(tape, VT(z_hat), P[p + ".0.weight"], P[p + ".0.bias"], pad=1, act_out=True)
+    u = E.conv2d(tape, VT(u, ACT_GELU), P[p + ".2.0.weight"], P[p + ".2.0.bias"], pad=1, pixel_shuffle=2, act_out=True)
+    u = E.conv2d(tape, VT(u, ACT_GELU), P[p + ".4.weight"], P[p + ".4.bias"], pad=1, act_out=True)
+    u = E.conv2d(tape, VT(u, ACT_GELU), P[p + ".6.0.weight"], P[p + ".6.0.bias"], pad=1, pixel_shuffle=2, act_out=True)
     return E.conv2d(tape, VT(u, ACT_GELU), P[p + ".8.weight"], P[p + ".8.bias"], pad=1, out=out)
 
 
@@ -139,7 +139,7 @@ def _h_s_pair(tape, P, p1, p2, z_hat, out1, out2):
     for name, ps, last in ((".0", 0, False), (".2.0", 2, False), (".4", 0, False), (".6.0", 2, False), (".8", 0, True)):
         ts = E.conv2d_group(tape, xv, [P[p1 + name + ".weight"], P[p2 + name + ".weight"]],
                             [P[p1 + name + ".bias"], P[p2 + name + ".bias"]], pad=1, pixel_shuffle=ps,
-                            outs=[out1, out2] if last else None)
+                            outs=[out1, out2] if last else None, act_out=not last)
         xv = [VT(ts[0], ACT_GELU), VT(ts[1], ACT_GELU)]
     return ts
 
@@ -263,7 +263,7 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
         xvs = [VT(ms)] * nt + [VT(ss)] * nt
         for li in (0, 2, 4, 6, 8):
             ts = E.conv2d_group(tape, xvs, [P[f"{p}.{li}.weight"] for p in names], [P[f"{p}.{li}.bias"] for p in names],
-                                pad=1)
+                                pad=1, act_out=li != 8)
             xvs = [VT(t, ACT_GELU) for t in ts]
         mu_t, sc_t = ts[:nt], ts[nt:]
         LSs, pres = [], []
@@ -291,7 +291,7 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
         xvs = [VT(LS) for LS in LSs]
         for li in (0, 2, 4, 6):
             ts = E.conv2d_group(tape, xvs, [P[f"{p}.{li}.weight"] for p in lnames],
-                                [P[f"{p}.{li}.bias"] for p in lnames], pad=1)
+                                [P[f"{p}.{li}.bias"] for p in lnames], pad=1, act_out=True)
             xvs = [VT(t, ACT_GELU) for t in ts]
         E.conv2d_group(tape, xvs, [P[f"{p}.8.weight"] for p in lnames], [P[f"{p}.8.bias"] for p in lnames], pad=1,
                        outs=[Y_hat[:, i * sc_:(i + 1) * sc_] for i in idx], lrp_auxs=pres)

@@ -35,7 +35,8 @@ extern "C" {
 #define ICM_ACT_SQUARE 2   /* x*x: GDN's conv2d(x**2, gamma) (layers/gdn.py:68) */
 
 /* epilogues of the implicit-GEMM kernels */
-#define ICM_EPI_NONE 0        /* y = acc + bias */
+#define ICM_EPI_NONE 0        /* y = acc + bias.  NONE / RES / RES_GELU with y2 != NULL (forward): y2 = gelu(y) as well --
+                               * the activation materialised once for every consumer of this pre-activation */
 #define ICM_EPI_RES 1         /* y = acc + bias + res              (out += identity, layers.py:69) */
 #define ICM_EPI_RES_GELU 2    /* y = acc + bias + gelu(res)        (identity is a virtual GELU output) */
 #define ICM_EPI_GDN 3         /* y2 = n = acc + bias; y = aux * rsqrt(n)   (gdn.py:68-75) */
