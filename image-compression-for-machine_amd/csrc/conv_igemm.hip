@@ -66,6 +66,24 @@ __global__ __launch_bounds__(512, (TCO * TPX <= 3) ? 4 : 2) void conv_igemm_kern
     const int lw = __builtin_amdgcn_readfirstlane(wave) - 4;
     PlaneMap pm;
 
+    if (pg.dma) {
+      // activation-free operand with a linear patch layout: LDS-DMA (global_load_lds_dword).  No VGPR holds the data,
+      // so a loader wave keeps every element of its channels in flight at once instead of 12-16 loads per lane; the
+      // wave drains vmcnt before the barrier that publishes the buffer (barriers do not wait for DMAs)
+      plane_map_init(pm, pg, n0, iyb, ixb, lane);
+      stage_planes_dma(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 < nchunks) {
+          const int c8 = (chunk + 1) * d.ckm;
+          stage_planes_dma(P.x, pm, pg, c8 * 8, min(d.ckm, d.nchunks8 - c8) * 8, smem + ((chunk + 1) & 1) * bufsz, lw, lane);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+      }
+      return;
+    }
     if (pg.vec4) {
       plane_map_init_v4(pm, pg, n0, iyb, ixb, lane);
       stage_planes_v4<8>(P.x, pm, pg, 0, min(d.ckm, d.nchunks8) * 8, smem, lw);
@@ -554,7 +572,10 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
               (bg.CS % 4) == 0 && (bg.PWrow % 4) == 0 && (bg.PP % 4) == 0;
     for (int gi = 0; gi < ngroups; ++gi) v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[gi].x) & 15) == 0);
     pg.vec4 = v4 ? 1 : 0;
-    pg.dma = 0;
+    // LDS-DMA staging: no activation to apply, linear patch layout (stride-1 input sampling: no column-parity split),
+    // not the 16-byte halo-free path (4x the bytes per instruction)
+    static const int dma_on = getenv("ICM_CONV_DMA") ? atoi(getenv("ICM_CONV_DMA")) : 1;
+    pg.dma = (dma_on && !v4 && S_in == 1 && a.pro_act == ICM_ACT_NONE && bg.PWrow == bg.PW && bg.PP == bg.PH * bg.PW) ? 1 : 0;
     pg.pipe = 0;
     set_v4_pack(pg);
   }
