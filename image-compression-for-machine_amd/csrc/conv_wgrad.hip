@@ -293,6 +293,180 @@ __global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
   }
 }
 
+// ---- 3x3 stride-1 problems with activation-free operands: all NINE taps from one staging, DMA-only loaders ----------
+// The tap-group kernels above re-stage every pixel tile once per group of four taps (9 taps = 4 + 4 + 1: three stagings,
+// the last with three of four waves idle), and their loader waves are latency-bound.  Here the workgroup is EIGHT
+// MFMA waves and no loader wave: both operands are staged by LDS-DMA (global_load_lds_dword: no VGPRs, every element
+// of the next tile in flight while this one is multiplied), wave w owns tap w of all TA x TB tiles of the (a, b) block
+// and the tiles of the ninth tap are dealt round-robin (tile e -> wave e mod 8) -- 10-11 accumulator tiles per wave
+// for the 96 x 96 block, 4-5 for 64 x 64.  One staging serves all 81 (36) tile-taps: a third of the staged bytes per
+// FLOP of the tap-group kernels.  The bias gradient (row sums of the small-grid tile) comes from the A fragments wave 0
+// reads anyway.  Needs activation-free operands (materialised activations) and the linear patch layout.
+template <int TA, int TB>
+__global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = TA * TB;        // tiles per tap
+  constexpr int NX = (NT + 7) / 8;   // tiles of the ninth tap per wave (at most)
+  const PatchGeom& pg = d.pg;
+  const int npx = 1 << d.lgNPX, grow = npx + 1;
+  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
+  const int bufsz = gs_sz + gb_sz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WgPtrs G = d.g[blockIdx.y];
+  int bid = blockIdx.x;
+  if (d.xcd_order) {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  const int at = bid % d.natile; bid /= d.natile;
+  const int bt = bid % d.nbtile;
+  const int split = bid / d.nbtile;
+  const int a0 = at * TA * 32, b0 = bt * TB * 32;
+  const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
+  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+  const int OHW = d.OH * d.OW;
+  const long long HWb = (long long)pg.H * pg.W * 4;
+  const float* zero = icm_zero_page + lane;
+  const int nj = (pg.TIPH * pg.PW + 63) >> 6;
+
+  // LDS-DMA staging of pixel tile `it` of this workgroup's share into buffer (it & 1)
+  auto stage = [&](int it) {
+    int q = split + it * d.nsplit;
+    const int tx_i = q % d.tiles_x; q /= d.tiles_x;
+    const int ty_i = q % d.tiles_y;
+    const int tn_i = q / d.tiles_y;
+    const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
+    float* gsT = smem + (it & 1) * bufsz;
+    float* gbP = gsT + gs_sz;
+    {   // small-grid tile [a][pixel]: one channel row per DMA instruction, lane = pixel of the tile
+      const int tx = lane & TWm, ty = (lane >> d.lgTW) & THm, ti = lane >> (d.lgTW + d.lgTH);
+      const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
+      const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
+      const float* base = G.gs + ((long long)n * d.gs_bs + oy * d.OW + ox);
+      if (lane < npx) {
+        for (int r = wave; r < TA * 32; r += 8) {
+          const int a = a0 + r;
+          const float* pp = (pv && a < d.Ca) ? base + (long long)a * OHW : zero;
+          __builtin_amdgcn_global_load_lds(pp, gsT + r * grow, 4, 0, 0);
+        }
+      }
+    }
+    PlaneMap pm;
+    plane_map_init(pm, pg, n0, oy0 * d.S - d.pad, ox0 * d.S - d.pad, lane);
+    const char* gbb = reinterpret_cast<const char*>(G.gb);
+    for (int cl = wave; cl < TB * 32; cl += 8) {
+      const int c = b0 + cl;
+      const char* base = gbb + (long long)c * HWb;
+      float* slab = gbP + cl * pg.CS;
+#pragma unroll
+      for (int j = 0; j < ICM_MAXJ; ++j) {
+        if (j < nj && pm.loff[j] >= 0) {
+          const float* pp = (c < pg.C && pm.goff[j] >= 0) ? reinterpret_cast<const float*>(base + pm.goff[j]) : zero;
+          __builtin_amdgcn_global_load_lds(pp, slab + 64 * j, 4, 0, 0);
+        }
+      }
+    }
+  };
+
+  const int h = lane >> 5, l31 = lane & 31;
+  int boffs[TB];
+#pragma unroll
+  for (int u = 0; u < TB; ++u) boffs[u] = (u * 32 + l31) * pg.CS + d.tapoff[wave] + h * d.po_h;
+  int xoff[NX], xrow[NX];
+  int nx_w = 0;
+#pragma unroll
+  for (int x = 0; x < NX; ++x) {
+    const int e = wave + 8 * x;
+    if (e < NT) nx_w = x + 1;
+    const int ee = e < NT ? e : 0;
+    xoff[x] = ((ee % TB) * 32 + l31) * pg.CS + d.tapoff[8] + h * d.po_h;
+    xrow[x] = (ee / TB) * 32 * grow;
+  }
+  f32x16 acc[NT + NX];
+#pragma unroll
+  for (int i = 0; i < NT + NX; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  const bool do_bias = G.dbias_ws != nullptr && bt == 0 && wave == 0;
+  float bsum[TA];
+#pragma unroll
+  for (int u = 0; u < TA; ++u) bsum[u] = 0.0f;
+  const int pe_lane = d.pe[lane & 31];
+  const int nkp = npx >> 1;
+
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    if (it + 1 < niter) stage(it + 1);   // flies while this tile is multiplied
+    const float* gsT = smem + (it & 1) * bufsz;
+    const float* gbP = gsT + gs_sz;
+    const float* arow = gsT + l31 * grow + h;
+    float avA[TA], bvA[TB], axA[NX], bxA[NX], avB[TA], bvB[TB], axB[NX], bxB[NX];
+    auto fetch = [&](float (&av)[TA], float (&bv)[TB], float (&ax)[NX], float (&bx)[NX], int kn) {
+      const int po = __builtin_amdgcn_readlane(pe_lane, kn);
+#pragma unroll
+      for (int u = 0; u < TA; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
+#pragma unroll
+      for (int u = 0; u < TB; ++u) bv[u] = gbP[boffs[u] + po];
+#pragma unroll
+      for (int x = 0; x < NX; ++x) {
+        ax[x] = arow[xrow[x] + 2 * kn];
+        bx[x] = gbP[xoff[x] + po];
+      }
+    };
+    auto mma = [&](const float (&av)[TA], const float (&bv)[TB], const float (&ax)[NX], const float (&bx)[NX]) {
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+          acc[ta * TB + tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta * TB + tb], 0, 0, 0);
+#pragma unroll
+      for (int x = 0; x < NX; ++x)
+        if (x < nx_w) acc[NT + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[x], bx[x], acc[NT + x], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TA; ++u) bsum[u] += av[u];
+    };
+    fetch(avA, bvA, axA, bxA, 0);
+    for (int kp = 0; kp < nkp; kp += 2) {
+      fetch(avB, bvB, axB, bxB, kp + 1);
+      mma(avA, bvA, axA, bxA);
+      fetch(avA, bvA, axA, bxA, min(kp + 2, nkp - 1));
+      mma(avB, bvB, axB, bxB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's DMAs have landed before the barrier publishes them
+    __syncthreads();
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int u = 0; u < TA; ++u) {
+      const float sfull = bsum[u] + __shfl_xor(bsum[u], 32, 64);   // pixels 2kp (h = 0) + pixels 2kp+1 (h = 1)
+      const int a = a0 + u * 32 + l31;
+      if (h == 0 && a < d.Ca) G.dbias_ws[(long long)split * d.Ca + a] = sfull;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NT + NX; ++i) {
+    int tap, ta, tb;
+    if (i < NT) { tap = wave; ta = i / TB; tb = i % TB; }
+    else {
+      const int e = wave + 8 * (i - NT);
+      if (e >= NT) continue;
+      tap = 8; ta = e / TB; tb = e % TB;
+    }
+    const int b = b0 + tb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (a < d.Ca && b < pg.C)
+        G.ws[(((long long)split * d.ntaps + tap) * d.Ca + a) * pg.C + b] = acc[i][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- general kernel: accumulators = (tap, a-tile, b-tile) triples dealt to the four MFMA waves ----------------------
 template <int TA, int TB, int NACC>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
@@ -534,7 +708,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
 // test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4> (general kernel);
 // 3 = t33<3,3,1,1>, 4 = t33<6,6,2,2>, 5 = t33<3,6,1,2>, 6 = t33<6,3,2,1> (3 x 3 tiles per wave, one tap per workgroup);
 // XCD-aware workgroup order 0 / 1; -1 = automatic choice
-#define WG_NVARIANTS 8   /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems) */
+#define WG_NVARIANTS 10  /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems);
+                          * 8 / 9 = tap9<3,3> / tap9<2,2>: all nine taps from one DMA staging (3x3 s1 p1, no activation) */
 static int g_force_variant = -1, g_force_xcd = -1;
 
 struct WgPlan {
@@ -585,6 +760,15 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
         case 4: return t33(4, 6, 6);
         case 5: return t33(5, 3, 6);
         case 6: return t33(6, 6, 3);
+        case 8:
+        case 9: {   // all nine taps of a 3x3 stride-1 problem from one DMA staging: 96 x 96 (8) or 64 x 64 (9) blocks
+          const int t = v == 8 ? 3 : 2;
+          if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.act_s == ICM_ACT_NONE &&
+                a.act_b == ICM_ACT_NONE) || lds_of(t, t) > 160 * 1024)
+            return false;
+          p.ta = t; p.tb = t; p.nacc = 9; p.tpg = 9; p.ws = v;
+          return true;
+        }
         case 7:   // 96 x 96 (a, b) block, four taps per workgroup (one per MFMA wave), no K split
           if (lds_of(3, 3) > 160 * 1024) return false;
           p.ta = 3; p.tb = 3; p.nacc = 9; p.tpg = std::min(ntaps, 4); p.ws = 7;
@@ -625,13 +809,20 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       // 100 % against 56 %) that idling the waves without a tap in the last tap group (9 taps = 4 + 4 + 1) still wins
       const double pad64 = (double)cdiv(a.Ca, 64) * 64 * cdiv(a.Cb, 64) * 64;
       const double pad96 = (double)cdiv(a.Ca, 96) * 96 * cdiv(a.Cb, 96) * 96 * (4.0 * cdiv(ntaps, 4) / ntaps);
-      ok = (ntaps > 1 && pad96 * 1.1 < pad64 && variant(7)) || variant(1);
+      // activation-free 3x3 stride-1 problems whose channels fit 96-wide blocks, with many pixels: the nine-tap
+      // single-staging kernel (96 -> 96 @ 64x64 x6: 92 TF against 65 for the tap-group kernel and 54 for <2,2,9>).  For
+      // the 4 096-pixel slice-chain problems <2,2,9> (two workgroups per CU, 64 tiles per problem) stays ahead
+      // (77 vs 71 TF at 480 -> 224 x10; profiles/r02_tune_wgrad_tap9.txt), as it does over the 64 x 64 tap9 form.
+      static const int tap9_on = getenv("ICM_WG_TAP9") ? atoi(getenv("ICM_WG_TAP9")) : 1;
+      const double p96 = (double)cdiv(a.Ca, 96) * 96 * cdiv(a.Cb, 96) * 96;
+      ok = tap9_on && ntaps == 9 && p96 <= pad64 && (long long)a.N * a.OH * a.OW >= 16384 && variant(8);
+      if (!ok) ok = (ntaps > 1 && pad96 * 1.1 < pad64 && variant(7)) || variant(1);
     }
     else ok = variant(0);
     if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
     if (ok) {
       p.lds = lds_of(p.ta, p.tb);
-      if (p.ws && p.ws != 7) {
+      if (p.ws && p.ws < 7) {
         const int wk = 4 / ((p.ta / 3) * (p.tb / 3));
         if (wk > 1) p.lds = std::max(p.lds, (size_t)(p.ta / 3) * (p.tb / 3) * std::min(wk - 1, 2) * 9 * 16 * 64 * 4);
       }
@@ -748,7 +939,9 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ws == 7) fn = wgrad_t33_kernel<3, 3, 1, 1, true>;
+  if (p.ws == 8) fn = wgrad_tap9_kernel<3, 3>;
+  else if (p.ws == 9) fn = wgrad_tap9_kernel<2, 2>;
+  else if (p.ws == 7) fn = wgrad_t33_kernel<3, 3, 1, 1, true>;
   else if (p.ws == 3) fn = wgrad_t33_kernel<3, 3, 1, 1>;
   else if (p.ws == 4) fn = wgrad_t33_kernel<6, 6, 2, 2>;
   else if (p.ws == 5) fn = wgrad_t33_kernel<3, 6, 1, 2>;

@@ -9,7 +9,7 @@ from icm_amd import _lib, engine as E
 
 lib = _lib.lib()
 dev = torch.device("cuda:0")
-NV = 8
+NV = 10
 
 # name, N, Cb(in), H, W, Ca(out), k, stride, group
 SHAPES = [
@@ -30,6 +30,12 @@ SHAPES = [
     ("3x3 128->64 @16 x10", 16, 128, 16, 16, 64, 3, 1, 10),
     ("3x3 64->32 @16 x10", 16, 64, 16, 16, 32, 3, 1, 10),
     ("3x3 64->32 @16 x2", 16, 64, 16, 16, 32, 3, 1, 2),
+    ("3x3 176->128 @16 x10", 16, 176, 16, 16, 128, 3, 1, 10),
+    ("3x3 512->224 @16 x5", 16, 512, 16, 16, 224, 3, 1, 5),
+    ("3x3 224->176 @16 x2", 16, 224, 16, 16, 176, 3, 1, 2),
+    ("3x3 160->160 @16 x6", 16, 160, 16, 16, 160, 3, 1, 6),
+    ("3x3 320->320 @16", 16, 320, 16, 16, 320, 3, 1, 1),
+    ("3x3 576->224 @16 x12", 16, 576, 16, 16, 224, 3, 1, 12),
     # virtual-GELU inputs (what most 3x3 / RU layers see in the step): name ends with "gelu"
     ("3x3 96->96 @64 x6 gelu", 16, 96, 64, 64, 96, 3, 1, 6),
     ("3x3 224->176 @16 x11 gelu", 16, 224, 16, 16, 176, 3, 1, 11),
