@@ -93,6 +93,9 @@ def _key(t: torch.Tensor):
 # GELU is evaluated once per element instead of once per consumer (x co-blocks), and activation-free operands are
 # eligible for the LDS-DMA staging of the weight-gradient loaders.  ICM_MATERIALIZE=0 keeps everything virtual.
 _MATERIALIZE = _os.environ.get("ICM_MATERIALIZE", "1") != "0"
+# launches below this many output pixels are host- / launch-bound (the 8x8 block maps of stf6: 1 024 pixels at B=16):
+# the extra tensor per layer costs more on the host than the saved GELU evaluations are worth on the device
+_MAT_MIN_PIXELS = int(_os.environ.get("ICM_MAT_MIN_PIXELS", "2048"))
 
 
 def _operand(tape, xv: "VT"):
@@ -451,7 +454,7 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
         assert res is None
         epi, aux = EPI_LRP, lrp_aux
         y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    elif act_out and _MATERIALIZE:
+    elif act_out and _MATERIALIZE and N * OH * OW >= _MAT_MIN_PIXELS:
         y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
         tape.mat[_key(y)] = y2
     conv_launch(tape, xf, wp, b, y, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, transposed=transposed,
@@ -642,7 +645,7 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
             resf, epi = [t for t, _ in rops], EPI_RES
         else:
             resf, epi = [r.t for r in ress], (EPI_RES_GELU if ress[0].act == ACT_GELU else EPI_RES)
-    if act_out and _MATERIALIZE and not lrp:
+    if act_out and _MATERIALIZE and not lrp and N * OH * OW >= _MAT_MIN_PIXELS:
         y2s = [new(oshape, x0.device) for _ in range(n)]
         for y, y2 in zip(ys, y2s):
             tape.mat[_key(y)] = y2
