@@ -302,11 +302,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_t33_kernel(const WgDesc d) {
 // for the 96 x 96 block, 4-5 for 64 x 64.  One staging serves all 81 (36) tile-taps: a third of the staged bytes per
 // FLOP of the tap-group kernels.  The bias gradient (row sums of the small-grid tile) comes from the A fragments wave 0
 // reads anyway.  Needs activation-free operands (materialised activations) and the linear patch layout.
-template <int TA, int TB>
+// TPW = own taps per wave: 1 for 3x3 (8 + 1 taps), 3 for 5x5 (24 + 1 taps: wave w owns taps w, w + 8, w + 16; the A
+// fragments are shared by all of a wave's taps, so a 96 x 32 block costs 3 A + 3-4 B reads per 9-10 MFMAs).
+template <int TA, int TB, int TPW = 1>
 __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = TA * TB;        // tiles per tap
-  constexpr int NX = (NT + 7) / 8;   // tiles of the ninth tap per wave (at most)
+  constexpr int NX = (NT + 7) / 8;   // tiles of the last tap per wave (at most)
+  constexpr int TLAST = 8 * TPW;     // the tap whose tiles are dealt round-robin
   const PatchGeom& pg = d.pg;
   const int npx = 1 << d.lgNPX, grow = npx + 1;
   const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
@@ -371,9 +374,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
   };
 
   const int h = lane >> 5, l31 = lane & 31;
-  int boffs[TB];
+  int boffs[TPW][TB];
 #pragma unroll
-  for (int u = 0; u < TB; ++u) boffs[u] = (u * 32 + l31) * pg.CS + d.tapoff[wave] + h * d.po_h;
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int u = 0; u < TB; ++u) boffs[j][u] = (u * 32 + l31) * pg.CS + d.tapoff[wave + 8 * j] + h * d.po_h;
   int xoff[NX], xrow[NX];
   int nx_w = 0;
 #pragma unroll
@@ -381,12 +386,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
     const int e = wave + 8 * x;
     if (e < NT) nx_w = x + 1;
     const int ee = e < NT ? e : 0;
-    xoff[x] = ((ee % TB) * 32 + l31) * pg.CS + d.tapoff[8] + h * d.po_h;
+    xoff[x] = ((ee % TB) * 32 + l31) * pg.CS + d.tapoff[TLAST] + h * d.po_h;
     xrow[x] = (ee / TB) * 32 * grow;
   }
-  f32x16 acc[NT + NX];
+  f32x16 acc[TPW * NT + NX];
 #pragma unroll
-  for (int i = 0; i < NT + NX; ++i)
+  for (int i = 0; i < TPW * NT + NX; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
   const bool do_bias = G.dbias_ws != nullptr && bt == 0 && wave == 0;
@@ -404,28 +409,33 @@ __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
     const float* gsT = smem + (it & 1) * bufsz;
     const float* gbP = gsT + gs_sz;
     const float* arow = gsT + l31 * grow + h;
-    float avA[TA], bvA[TB], axA[NX], bxA[NX], avB[TA], bvB[TB], axB[NX], bxB[NX];
-    auto fetch = [&](float (&av)[TA], float (&bv)[TB], float (&ax)[NX], float (&bx)[NX], int kn) {
+    float avA[TA], bvA[TPW][TB], axA[NX], bxA[NX], avB[TA], bvB[TPW][TB], axB[NX], bxB[NX];
+    auto fetch = [&](float (&av)[TA], float (&bv)[TPW][TB], float (&ax)[NX], float (&bx)[NX], int kn) {
       const int po = __builtin_amdgcn_readlane(pe_lane, kn);
 #pragma unroll
       for (int u = 0; u < TA; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
 #pragma unroll
-      for (int u = 0; u < TB; ++u) bv[u] = gbP[boffs[u] + po];
+      for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int u = 0; u < TB; ++u) bv[j][u] = gbP[boffs[j][u] + po];
 #pragma unroll
       for (int x = 0; x < NX; ++x) {
         ax[x] = arow[xrow[x] + 2 * kn];
         bx[x] = gbP[xoff[x] + po];
       }
     };
-    auto mma = [&](const float (&av)[TA], const float (&bv)[TB], const float (&ax)[NX], const float (&bx)[NX]) {
+    auto mma = [&](const float (&av)[TA], const float (&bv)[TPW][TB], const float (&ax)[NX], const float (&bx)[NX]) {
 #pragma unroll
-      for (int ta = 0; ta < TA; ++ta)
+      for (int j = 0; j < TPW; ++j)
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb)
-          acc[ta * TB + tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta * TB + tb], 0, 0, 0);
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb)
+            acc[(j * TA + ta) * TB + tb] =
+                __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[j][tb], acc[(j * TA + ta) * TB + tb], 0, 0, 0);
 #pragma unroll
       for (int x = 0; x < NX; ++x)
-        if (x < nx_w) acc[NT + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[x], bx[x], acc[NT + x], 0, 0, 0);
+        if (x < nx_w) acc[TPW * NT + x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[x], bx[x], acc[TPW * NT + x], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < TA; ++u) bsum[u] += av[u];
     };
@@ -448,13 +458,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < NT + NX; ++i) {
+  for (int i = 0; i < TPW * NT + NX; ++i) {
     int tap, ta, tb;
-    if (i < NT) { tap = wave; ta = i / TB; tb = i % TB; }
+    if (i < TPW * NT) { tap = wave + 8 * (i / NT); ta = (i % NT) / TB; tb = i % TB; }
     else {
-      const int e = wave + 8 * (i - NT);
+      const int e = wave + 8 * (i - TPW * NT);
       if (e >= NT) continue;
-      tap = 8; ta = e / TB; tb = e % TB;
+      tap = TLAST; ta = e / TB; tb = e % TB;
     }
     const int b = b0 + tb * 32 + l31;
 #pragma unroll
@@ -708,7 +718,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
 // test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4> (general kernel);
 // 3 = t33<3,3,1,1>, 4 = t33<6,6,2,2>, 5 = t33<3,6,1,2>, 6 = t33<6,3,2,1> (3 x 3 tiles per wave, one tap per workgroup);
 // XCD-aware workgroup order 0 / 1; -1 = automatic choice
-#define WG_NVARIANTS 10  /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems);
+#define WG_NVARIANTS 11  /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems);
                           * 8 / 9 = tap9<3,3> / tap9<2,2>: all nine taps from one DMA staging (3x3 s1 p1, no activation) */
 static int g_force_variant = -1, g_force_xcd = -1;
 
@@ -769,6 +779,12 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
           p.ta = t; p.tb = t; p.nacc = 9; p.tpg = 9; p.ws = v;
           return true;
         }
+        case 10:   // all 25 taps of a 5x5 problem (stride 1 or 2) from one DMA staging: 96 x 32 blocks, three taps per wave
+          if (!(a.KH == 5 && a.KW == 5 && a.pad == 2 && a.act_s == ICM_ACT_NONE && a.act_b == ICM_ACT_NONE) ||
+              lds_of(3, 1) > 160 * 1024)
+            return false;
+          p.ta = 3; p.tb = 1; p.nacc = 10; p.tpg = 25; p.ws = v;
+          return true;
         case 7:   // 96 x 96 (a, b) block, four taps per workgroup (one per MFMA wave), no K split
           if (lds_of(3, 3) > 160 * 1024) return false;
           p.ta = 3; p.tb = 3; p.nacc = 9; p.tpg = std::min(ntaps, 4); p.ws = 7;
@@ -818,7 +834,12 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       ok = tap9_on && ntaps == 9 && p96 <= pad64 && (long long)a.N * a.OH * a.OW >= 16384 && variant(8);
       if (!ok) ok = (ntaps > 1 && pad96 * 1.1 < pad64 && variant(7)) || variant(1);
     }
-    else ok = variant(0);
+    else {
+      static const int tap25_on = getenv("ICM_WG_TAP25") ? atoi(getenv("ICM_WG_TAP25")) : 1;
+      ok = tap25_on && ntaps == 25 && (long long)a.N * a.OH * a.OW >= 16384 && variant(10);
+      if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;
+      if (!ok) ok = variant(0);
+    }
     if (ok && TI * p.PP > ICM_MAXJ * 64) ok = false;   // PlaneMap capacity
     if (ok) {
       p.lds = lds_of(p.ta, p.tb);
@@ -939,7 +960,8 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ws == 8) fn = wgrad_tap9_kernel<3, 3>;
+  if (p.ws == 10) fn = wgrad_tap9_kernel<3, 1, 3>;
+  else if (p.ws == 8) fn = wgrad_tap9_kernel<3, 3>;
   else if (p.ws == 9) fn = wgrad_tap9_kernel<2, 2>;
   else if (p.ws == 7) fn = wgrad_t33_kernel<3, 3, 1, 1, true>;
   else if (p.ws == 3) fn = wgrad_t33_kernel<3, 3, 1, 1>;

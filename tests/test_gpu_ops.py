@@ -485,9 +485,11 @@ def _wgrad_ref(x, w, b, g, k, s, tr):
 WG_CASES = [
     # name, N, Cin, H, W, Cout, k, stride, transposed, variants to force (conv_wgrad.hip: 0-2 general kernel <2,1,7> /
     # <2,2,9> / <4,4,4>; 3-6 the 3x3-tiles-per-wave kernel <3,3,1,1> / <6,6,2,2> / <3,6,1,2> / <6,3,2,1>; 7 its
-    # tap-per-wave form; 8 / 9 the nine-tap single-staging DMA kernel tap9<3,3> / tap9<2,2>)
-    ("wg_c5s2", 3, 40, 36, 20, 72, 5, 2, False, (0, 1, 3, 7)),   # <4,4,4> and the 192-wide tiles need > 160 KB of LDS here
-    ("wg_t5s2", 2, 48, 10, 12, 40, 5, 2, True, (0, 1)),
+    # tap-per-wave form; 8 / 9 the nine-tap single-staging DMA kernel tap9<3,3> / tap9<2,2>; 10 its 25-tap 5x5 form)
+    ("wg_c5s2", 3, 40, 36, 20, 72, 5, 2, False, (0, 1, 3, 7, 10)),   # <4,4,4> and the 192-wide tiles need > 160 KB of LDS here
+    ("wg_t5s2", 2, 48, 10, 12, 40, 5, 2, True, (0, 1, 10)),
+    ("wg_c5s2_192_100", 2, 192, 24, 40, 100, 5, 2, False, (10,)),    # 25 taps from one staging: several blocks, channel tails
+    ("wg_c5s1", 2, 48, 12, 20, 72, 5, 1, False, (0, 10)),
     ("wg_c3s1", 3, 48, 20, 12, 80, 3, 1, False, (0, 1, 2, 3, 5, 6, 7, 8, 9)),
     ("wg_c3s1_96_96", 2, 96, 16, 32, 96, 3, 1, False, (-1, 1, 7, 8, 9)),    # automatic choice: nine taps per workgroup (8)
     ("wg_c3s1_192_100", 2, 192, 16, 16, 100, 3, 1, False, (7, 8, 9)),
