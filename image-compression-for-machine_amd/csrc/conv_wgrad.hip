@@ -477,6 +477,171 @@ __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
   }
 }
 
+// ---- 1x1 problems with activation-free operands: eight MFMA waves, DMA-only staging ---------------------------------
+// Same idea as the tap kernels above for problems without taps: no loader waves; the (TA x TB) block is covered by
+// WA x WB groups of 3 x 3 tiles and the 8 / (WA * WB) waves of a group split the pixel pairs (kp = wk mod WK) and fold
+// their partial sums through LDS at the end (fixed order).  The bias gradient comes from the A fragments of the wb == 0
+// waves, folded over the K split the same way.
+template <int TA, int TB, int WA, int WB>
+__global__ __launch_bounds__(512, 2) void wgrad_dma1_kernel(const WgDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(TA == 3 * WA && TB == 3 * WB && (WA * WB == 1 || WA * WB == 2 || WA * WB == 4), "3 x 3 tiles per wave");
+  constexpr int WK = 8 / (WA * WB);
+  const PatchGeom& pg = d.pg;
+  const int npx = 1 << d.lgNPX, grow = npx + 1;
+  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
+  const int bufsz = gs_sz + gb_sz;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const WgPtrs G = d.g[blockIdx.y];
+  int bid = blockIdx.x;
+  if (d.xcd_order) {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  const int at = bid % d.natile; bid /= d.natile;
+  const int bt = bid % d.nbtile;
+  const int split = bid / d.nbtile;
+  const int a0 = at * TA * 32, b0 = bt * TB * 32;
+  const int niter = (d.ntiles - split + d.nsplit - 1) / d.nsplit;
+  const int TWm = (1 << d.lgTW) - 1, THm = (1 << d.lgTH) - 1;
+  const int OHW = d.OH * d.OW;
+  const long long HW = (long long)pg.H * pg.W;
+  const float* zero = icm_zero_page + lane;
+
+  // both operands of a 1x1 stride-1 problem are [channel][pixel of the tile]: one channel row per DMA instruction
+  auto stage = [&](int it) {
+    int q = split + it * d.nsplit;
+    const int tx_i = q % d.tiles_x; q /= d.tiles_x;
+    const int ty_i = q % d.tiles_y;
+    const int tn_i = q / d.tiles_y;
+    const int ox0 = tx_i << d.lgTW, oy0 = ty_i << d.lgTH, n0 = tn_i << d.lgTI;
+    float* gsT = smem + (it & 1) * bufsz;
+    float* gbP = gsT + gs_sz;
+    const int tx = lane & TWm, ty = (lane >> d.lgTW) & THm, ti = lane >> (d.lgTW + d.lgTH);
+    const int n = n0 + ti, oy = oy0 + ty, ox = ox0 + tx;
+    const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
+    const float* abase = G.gs + ((long long)n * d.gs_bs + oy * d.OW + ox);
+    const float* bbase = G.gb + ((long long)n * pg.bs + oy * pg.W + ox);
+    if (lane < npx) {
+      for (int r = wave; r < TA * 32; r += 8) {
+        const int a = a0 + r;
+        __builtin_amdgcn_global_load_lds((pv && a < d.Ca) ? abase + (long long)a * OHW : zero, gsT + r * grow, 4, 0, 0);
+      }
+      for (int r = wave; r < TB * 32; r += 8) {
+        const int c = b0 + r;
+        __builtin_amdgcn_global_load_lds((pv && c < pg.C) ? bbase + (long long)c * HW : zero, gbP + r * pg.CS, 4, 0, 0);
+      }
+    }
+  };
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wk = wave % WK, wsp = wave / WK;
+  const int wa = wsp / WB, wb = wsp % WB;
+  int boffs[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) boffs[u] = ((wb * 3 + u) * 32 + l31) * pg.CS + h;
+  f32x16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+  float bsum[3] = {0.0f, 0.0f, 0.0f};
+  const int nkp = npx >> 1;
+
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    if (it + 1 < niter) stage(it + 1);
+    const float* gsT = smem + (it & 1) * bufsz;
+    const float* gbP = gsT + gs_sz;
+    const float* arow = gsT + (wa * 3 * 32 + l31) * grow + h;
+    float avA[3], bvA[3], avB[3], bvB[3];
+    auto fetch = [&](float (&av)[3], float (&bv)[3], int kn) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) bv[u] = gbP[boffs[u] + 2 * kn];
+    };
+    auto mma = [&](const float (&av)[3], const float (&bv)[3]) {
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb)
+          acc[ta * 3 + tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ta], bv[tb], acc[ta * 3 + tb], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) bsum[u] += av[u];
+    };
+    fetch(avA, bvA, wk);
+    for (int kp = wk; kp < nkp; kp += 2 * WK) {
+      fetch(avB, bvB, min(kp + WK, nkp - 1));
+      mma(avA, bvA);
+      fetch(avA, bvA, min(kp + 2 * WK, nkp - 1));
+      if (kp + WK < nkp) mma(avB, bvB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // ---- fold the WK partial sums of every (wa, wb) group through LDS (the staging buffers are free now)
+  constexpr int SET = 9 * 16 * 64;
+  constexpr int SLOTS = (WK - 1) < 2 ? (WK - 1) : 2;
+  float* red = smem + wsp * SLOTS * SET;
+#pragma unroll
+  for (int r0 = 1; r0 < WK; r0 += SLOTS) {
+    if (wk >= r0 && wk < r0 + SLOTS) {
+      float* dst = red + (wk - r0) * SET;
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64 + lane] = acc[i][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+      for (int k = 0; k < SLOTS && r0 + k < WK; ++k)
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] += red[k * SET + (i * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  // bias gradient: row sums seen by the wb == 0 waves, folded over h and over the K split in wave order
+  if (G.dbias_ws != nullptr && bt == 0) {
+    float* bred = smem;   // [WA][WK][96] after the accumulator fold (barrier above)
+    if (wb == 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const float sfull = bsum[u] + __shfl_xor(bsum[u], 32, 64);
+        if (h == 0) bred[(wa * WK + wk) * 96 + u * 32 + l31] = sfull;
+      }
+    }
+    __syncthreads();
+    if (wb == 0 && wk == 0 && h == 0) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        float t = 0.0f;
+        for (int k = 0; k < WK; ++k) t += bred[(wa * WK + k) * 96 + u * 32 + l31];
+        const int a = a0 + (wa * 3 + u) * 32 + l31;
+        if (a < d.Ca) G.dbias_ws[(long long)split * d.Ca + a] = t;
+      }
+    }
+  }
+  if (wk != 0) return;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int ta = wa * 3 + i / 3, tb = wb * 3 + i % 3;
+    const int b = b0 + tb * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = a0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (a < d.Ca && b < pg.C) G.ws[((long long)split * d.Ca + a) * pg.C + b] = acc[i][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- general kernel: accumulators = (tap, a-tile, b-tile) triples dealt to the four MFMA waves ----------------------
 template <int TA, int TB, int NACC>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(const WgDesc d) {
@@ -718,7 +883,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
 // test hooks (icm_debug_force_wgrad_cfg): kernel variant 0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4> (general kernel);
 // 3 = t33<3,3,1,1>, 4 = t33<6,6,2,2>, 5 = t33<3,6,1,2>, 6 = t33<6,3,2,1> (3 x 3 tiles per wave, one tap per workgroup);
 // XCD-aware workgroup order 0 / 1; -1 = automatic choice
-#define WG_NVARIANTS 11  /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems);
+#define WG_NVARIANTS 15  /* 7 = t33<3,3,1,1,tap-per-wave>: 96 x 96 x 4 taps per workgroup (3x3 problems);
                           * 8 / 9 = tap9<3,3> / tap9<2,2>: all nine taps from one DMA staging (3x3 s1 p1, no activation) */
 static int g_force_variant = -1, g_force_xcd = -1;
 
@@ -764,8 +929,20 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       p.ta = ta; p.tb = tb; p.nacc = 9; p.tpg = 1; p.ws = v;
       return true;
     };
+    auto dma1 = [&](int v, int ta, int tb) -> bool {   // 1x1, activation-free: 8 MFMA waves, DMA-only staging
+      if (!(ntaps == 1 && a.stride == 1 && a.pad == 0 && a.act_s == ICM_ACT_NONE && a.act_b == ICM_ACT_NONE)) return false;
+      const int groups = (ta / 3) * (tb / 3), wk = 8 / groups;
+      const size_t fold = (size_t)groups * std::min(wk - 1, 2) * 9 * 16 * 64 * 4;
+      if (std::max(lds_of(ta, tb), fold) > 160 * 1024) return false;
+      p.ta = ta; p.tb = tb; p.nacc = 9; p.tpg = 1; p.ws = v;
+      return true;
+    };
     auto variant = [&](int v) -> bool {   // kernel variant v for this tile size; false if its LDS does not fit
       switch (v) {
+        case 11: return dma1(11, 6, 6);
+        case 12: return dma1(12, 3, 6);
+        case 13: return dma1(13, 6, 3);
+        case 14: return dma1(14, 3, 3);
         case 3: return t33(3, 3, 3);
         case 4: return t33(4, 6, 6);
         case 5: return t33(5, 3, 6);
@@ -812,8 +989,27 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
         if (cost < bestc - 1e-9) { bestc = cost; bestv = c.v; }
       }
       ok = bestv >= 0 && variant(bestv);
+      // activation-free operands: the DMA-only kernel (8 MFMA waves).  Staging costs it little, so the block is chosen
+      // by padded area alone; among equal areas the four-way K split (96 x 192 / 192 x 96 blocks) measured best:
+      // 192 -> 192 @128: <6,3> 75.8, <3,6> 73.4, <6,6> 68.3, <3,3> 63.9 TF against 58.7 for the loader-wave kernel
+      // (profiles/r02_tune_wgrad_dma1.txt)
+      static const int dma1_on = getenv("ICM_WG_DMA1") ? atoi(getenv("ICM_WG_DMA1")) : 1;
+      if (ok && dma1_on && a.act_s == ICM_ACT_NONE && a.act_b == ICM_ACT_NONE && a.stride == 1 && a.pad == 0) {
+        static const struct { int v, ta, tb; } dc[] = {{13, 6, 3}, {12, 3, 6}, {11, 6, 6}, {14, 3, 3}};
+        double ba = 1e300;
+        int bv = -1;
+        for (const auto& c : dc) {
+          const double area = (double)cdiv(a.Ca, 32 * c.ta) * 32 * c.ta * cdiv(a.Cb, 32 * c.tb) * 32 * c.tb;
+          if (area < ba - 1e-9) {
+            WgPlan keep = p;
+            if (variant(c.v)) { ba = area; bv = c.v; }
+            p = keep;
+          }
+        }
+        if (bv >= 0) variant(bv);
+      }
       // a smaller pixel tile is only worth it for the big tiles that need it (<6,6> does not fit 64 pixels)
-      if (ok && lg == 6) {
+      if (ok && lg == 6 && p.ws < 11) {
         const double area6 = (double)cdiv(a.Ca, 32 * p.ta) * 32 * p.ta * cdiv(a.Cb, 32 * p.tb) * 32 * p.tb *
                              std::max(1.0, 5.2 * (1.0 / p.ta + 1.0 / p.tb));
         const double area66 = (double)cdiv(a.Ca, 192) * 192 * cdiv(a.Cb, 192) * 192 * std::max(1.0, 5.2 / 3.0);
@@ -846,6 +1042,10 @@ static int plan_wgrad(const icm_wgrad_args& a, WgPlan& p, int nproblems = 1) {
       if (p.ws && p.ws < 7) {
         const int wk = 4 / ((p.ta / 3) * (p.tb / 3));
         if (wk > 1) p.lds = std::max(p.lds, (size_t)(p.ta / 3) * (p.tb / 3) * std::min(wk - 1, 2) * 9 * 16 * 64 * 4);
+      }
+      if (p.ws >= 11) {
+        const int groups = (p.ta / 3) * (p.tb / 3), wk = 8 / groups;
+        p.lds = std::max(p.lds, (size_t)groups * std::min(wk - 1, 2) * 9 * 16 * 64 * 4);
       }
     }
   }
@@ -960,7 +1160,11 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ws == 10) fn = wgrad_tap9_kernel<3, 1, 3>;
+  if (p.ws == 11) fn = wgrad_dma1_kernel<6, 6, 2, 2>;
+  else if (p.ws == 12) fn = wgrad_dma1_kernel<3, 6, 1, 2>;
+  else if (p.ws == 13) fn = wgrad_dma1_kernel<6, 3, 2, 1>;
+  else if (p.ws == 14) fn = wgrad_dma1_kernel<3, 3, 1, 1>;
+  else if (p.ws == 10) fn = wgrad_tap9_kernel<3, 1, 3>;
   else if (p.ws == 8) fn = wgrad_tap9_kernel<3, 3>;
   else if (p.ws == 9) fn = wgrad_tap9_kernel<2, 2>;
   else if (p.ws == 7) fn = wgrad_t33_kernel<3, 3, 1, 1, true>;

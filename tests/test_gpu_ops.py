@@ -485,7 +485,8 @@ def _wgrad_ref(x, w, b, g, k, s, tr):
 WG_CASES = [
     # name, N, Cin, H, W, Cout, k, stride, transposed, variants to force (conv_wgrad.hip: 0-2 general kernel <2,1,7> /
     # <2,2,9> / <4,4,4>; 3-6 the 3x3-tiles-per-wave kernel <3,3,1,1> / <6,6,2,2> / <3,6,1,2> / <6,3,2,1>; 7 its
-    # tap-per-wave form; 8 / 9 the nine-tap single-staging DMA kernel tap9<3,3> / tap9<2,2>; 10 its 25-tap 5x5 form)
+    # tap-per-wave form; 8 / 9 the nine-tap single-staging DMA kernel tap9<3,3> / tap9<2,2>; 10 its 25-tap 5x5 form;
+    # 11-14 the DMA-only 1x1 kernel dma1<6,6> / <3,6> / <6,3> / <3,3>)
     ("wg_c5s2", 3, 40, 36, 20, 72, 5, 2, False, (0, 1, 3, 7, 10)),   # <4,4,4> and the 192-wide tiles need > 160 KB of LDS here
     ("wg_t5s2", 2, 48, 10, 12, 40, 5, 2, True, (0, 1, 10)),
     ("wg_c5s2_192_100", 2, 192, 24, 40, 100, 5, 2, False, (10,)),    # 25 taps from one staging: several blocks, channel tails
@@ -494,10 +495,10 @@ WG_CASES = [
     ("wg_c3s1_96_96", 2, 96, 16, 32, 96, 3, 1, False, (-1, 1, 7, 8, 9)),    # automatic choice: nine taps per workgroup (8)
     ("wg_c3s1_192_100", 2, 192, 16, 16, 100, 3, 1, False, (7, 8, 9)),
     ("wg_c3s1_224_176_ragged", 3, 224, 12, 10, 176, 3, 1, False, (8, 9)),   # several (a, b) blocks, ragged tiles, channel tails
-    ("wg_c1_96_192", 2, 96, 16, 16, 192, 1, 1, False, (0, 1, 2, 3, 4, 5, 6)),
-    ("wg_c1_130_70", 3, 130, 12, 20, 70, 1, 1, False, (0, 1, 2, 3, 4, 5, 6)),
-    ("wg_c1_200_400", 2, 200, 8, 24, 400, 1, 1, False, (3, 4, 5, 6)),      # several (a, b) blocks per variant
-    ("wg_c1_192_192_big", 4, 192, 64, 32, 192, 1, 1, False, (-1, 4)),      # the automatic choice (<6,6>, 32-pixel tiles)
+    ("wg_c1_96_192", 2, 96, 16, 16, 192, 1, 1, False, (0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14)),
+    ("wg_c1_130_70", 3, 130, 12, 20, 70, 1, 1, False, (0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14)),
+    ("wg_c1_200_400", 2, 200, 8, 24, 400, 1, 1, False, (3, 4, 5, 6, 11, 12, 13, 14)),   # several (a, b) blocks per variant
+    ("wg_c1_192_192_big", 4, 192, 64, 32, 192, 1, 1, False, (-1, 4, 11)),  # the automatic choice (DMA <6,6>, 32-pixel tiles)
     ("wg_c3_tiny", 4, 24, 4, 4, 48, 3, 1, False, (0, 1, 2, 3, 7, 8, 9)),
 ]
 

@@ -9,7 +9,7 @@ from icm_amd import _lib, engine as E
 
 lib = _lib.lib()
 dev = torch.device("cuda:0")
-NV = 11
+NV = 15
 
 # name, N, Cb(in), H, W, Ca(out), k, stride, group
 SHAPES = [
