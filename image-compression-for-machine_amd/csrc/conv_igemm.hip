@@ -506,7 +506,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   Geometry bg{}, bg1{};
   const int ncfg = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
   for (int i = 0; i < ncfg; ++i) {
-    if (g_force_cfg >= 0 && i != g_force_cfg) continue;
+    if (g_force_cfg >= 0 && g_force_cfg < 100 && i != g_force_cfg) continue;
     const KernelCfg& c = kCfgs[i];
     const int bpx = c.wpx * c.tpx * 32, bco_t = c.wco * c.tco;
     Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps, c.tco * c.tpx);
@@ -543,6 +543,37 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     bg = bg1;
   }
   const KernelCfg& c = kCfgs[best];
+  // Latency-bound launches (few workgroups whatever the tiling): the 8-wave K-split kernel (conv_ks8.hip).  Needs
+  // stride-1 sampling, no operand activation, the GDN / AXPY2 epilogues excluded (they belong to pointwise launches),
+  // and the step table in one VGPR (ckm * ntaps <= 64, as here).  OFF by default: measured on the training step it wins
+  // on the deep-K, wide-output chain layers (224 -> 176 @16x16: 60 -> 51 us, 480 -> 224: 116 -> 100 us) but loses on
+  // narrow outputs (64 -> 32: 17 -> 29 us), tiny maps and the 32x32 transposed 5x5 classes -- 338.5 -> 334.0 img/s over
+  // the whole step (same-box A/B); ICM_CONV_KS8=1 reproduces it, the parity tests force it (cfg 100 / 101).
+  int ks8_tco = 0;
+  {
+    static const int ks8_on = getenv("ICM_CONV_KS8") ? atoi(getenv("ICM_CONV_KS8")) : 0;
+    static const long long ks8_max = getenv("ICM_CONV_KS8_MAXWG") ? atoll(getenv("ICM_CONV_KS8_MAXWG")) : 768;
+    const bool epi_ok = a.epi == ICM_EPI_NONE || a.epi == ICM_EPI_RES || a.epi == ICM_EPI_RES_GELU ||
+                        a.epi == ICM_EPI_MUL_DGELU || a.epi == ICM_EPI_LRP || a.epi == ICM_EPI_RES_MUL_DGELU;
+    if ((ks8_on && g_force_cfg < 0 || g_force_cfg == 100 || g_force_cfg == 101) && S_in == 1 && ntaps > 1 &&
+        a.pro_act == ICM_ACT_NONE && epi_ok) {
+      const int tco = g_force_cfg == 101 ? 1 : (g_force_cfg == 100 ? 2 : (ncot >= 2 ? 2 : 1));
+      const int bpx = tco == 2 ? 64 : 128;
+      Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps, 4);
+      // more K per barrier than the staged kernel needs: every wave should find >= 2 of its sub-steps in a chunk
+      int ckm = std::max(1, std::min(nchunks8, 64 / ntaps));
+      while (ckm > 1 && (size_t)2 * ckm * 8 * g.CS * sizeof(float) > 96 * 1024) --ckm;
+      g.ckm = ckm;
+      g.lds_bytes = std::max((size_t)2 * ckm * 8 * g.CS * sizeof(float), (size_t)8 * 4 * 16 * 64 * sizeof(float));
+      const long long blocks = (long long)cdiv(ncot, tco) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
+      const bool fits = g.lds_bytes <= 160 * 1024 && (1 << g.lgTI) * g.PH * g.PW <= ICM_MAXJ * 64 && g.PWrow == g.PW &&
+                        g.PP == g.PH * g.PW;
+      if (fits && (g_force_cfg >= 100 || blocks <= ks8_max)) {
+        ks8_tco = tco;
+        bg = g;
+      }
+    }
+  }
 
   ConvDesc d;
   for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
@@ -590,7 +621,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   d.ntaps = ntaps;
   d.lgTW = bg.lgTW; d.lgTH = bg.lgTH; d.lgTI = bg.lgTI;
   d.tiles_x = bg.tiles_x; d.tiles_y = bg.tiles_y; d.tiles_n = bg.tiles_n;
-  d.ncot = ncot; d.nchunks8 = nchunks8; d.ckm = bg.ckm; d.ncb = cdiv(ncot, c.wco * c.tco);
+  d.ncot = ncot; d.nchunks8 = nchunks8; d.ckm = bg.ckm; d.ncb = cdiv(ncot, ks8_tco ? ks8_tco : c.wco * c.tco);
   d.epi = a.epi; d.accum = a.accum;
   for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapoff[t] = 0;
   for (int t = 0; t < ntaps; ++t) {
@@ -600,6 +631,11 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   }
   const long long nblk = (long long)d.ncb * d.tiles_x * d.tiles_y * d.tiles_n;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
+  if (ks8_tco) {
+    d.pg.vec4 = 0;
+    d.pg.dma = 1;
+    return launch_conv_ks8(d, ks8_tco, nblk, ngroups, bg.lds_bytes, stream);
+  }
   if (bg.lds_bytes > 64 * 1024 && !ensure_max_lds(reinterpret_cast<const void*>(c.fn))) return ICM_ERR_LAUNCH;
   hipLaunchKernelGGL(c.fn, dim3((unsigned)nblk, ngroups, 1), dim3(512), bg.lds_bytes, stream, d);
   ICM_CHECK_LAUNCH();

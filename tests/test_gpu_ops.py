@@ -752,3 +752,43 @@ def test_conv1x1_direct_kernel_fused_neighbours(which, golden_dir):
             test_gate_golden(golden_dir)
     finally:
         lib.icm_debug_force_conv1x1(-1)
+
+
+# ------------------------------------------------------------------------------------------ 8-wave K-split conv kernel
+KS8_CASES = [
+    # name, N, Cin, H, W, Cout, k, stride, transposed: stride-1 sampling problems of the slice-chain / hyper-path kind
+    ("ks8_c3_224_176", 2, 224, 16, 16, 176, 3, 1, False),
+    ("ks8_c3_64_32", 3, 64, 12, 20, 32, 3, 1, False),      # one co tile: the 32 x 128 block; ragged pixel tiles
+    ("ks8_c3_40_200_odd", 2, 40, 9, 7, 200, 3, 1, False),  # channel tails, fewer sub-steps than waves in the last chunk
+    ("ks8_c5s1_48_72", 2, 48, 12, 10, 72, 5, 1, False),    # 25 taps: two 8-channel groups per staged chunk
+    ("ks8_c3_8_64_tiny", 4, 8, 4, 4, 64, 3, 1, False),     # 9 sub-steps in total: one wave gets two, the others one
+]
+
+
+@pytest.mark.parametrize("case", KS8_CASES, ids=[c[0] for c in KS8_CASES])
+@pytest.mark.parametrize("cfg", [100, 101])
+def test_conv_ks8_kernel(case, cfg):
+    """the 8-wave K-split kernel forced on (100: 64 co x 64 px blocks, 101: 32 co x 128 px): forward and input gradient
+    (the dgrad of a stride-1 conv is the same kernel on the transposed weights) against torch, and the automatic path"""
+    from icm_amd import _lib
+    lib = _lib.lib()
+    try:
+        lib.icm_debug_force_conv_cfg(cfg)
+        test_conv_fwd_bwd(case)
+    finally:
+        lib.icm_debug_force_conv_cfg(-1)
+
+
+def test_conv_ks8_fused_neighbours():
+    """residual / LRP / GELU' epilogues and grouped launches through the K-split kernel: the grouped slice-chain test
+    and the dim-320 gate against the oracle with the kernel forced on"""
+    from icm_amd import _lib
+    lib = _lib.lib()
+    try:
+        lib.icm_debug_force_conv_cfg(100)
+        test_conv_group_shared_input_and_lrp_tail_vs_singles()
+        test_attention_gate_vs_oracle(320, 4, 2, 8)
+        lib.icm_debug_force_conv_cfg(101)
+        test_conv_group_shared_input_and_lrp_tail_vs_singles()
+    finally:
+        lib.icm_debug_force_conv_cfg(-1)
