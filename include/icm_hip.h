@@ -319,8 +319,11 @@ int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, 
               void* stream);
 
 /* ---- test hooks (process-global; used by the parity tests and tools/tune_conv.py only) ----------------------
- * force the implicit-GEMM tile configuration (index into the kernel table, -1 = automatic) / the weight-gradient
- * kernel variant (0 = <2,1,7>, 1 = <2,2,9>, 2 = <4,4,4>, 3 = <3,3,9> wave-split; -1 = automatic) and its XCD-aware
+ * force the implicit-GEMM tile configuration (index into the kernel table; 100 / 101 = the 8-wave K-split kernel of
+ * conv_ks8.hip with 64 co x 64 px / 32 co x 128 px blocks where it is eligible; -1 = automatic) / the weight-gradient
+ * kernel variant (0-2 general kernel <2,1,7> / <2,2,9> / <4,4,4>; 3-6 three-by-three tiles per wave <3,3> / <6,6> /
+ * <3,6> / <6,3>; 7 its tap-per-wave form; 8 / 9 nine taps from one DMA staging, 96 / 64-wide blocks; 10 the 25-tap
+ * 5x5 form; 11-14 the DMA-only 1x1 kernel <6,6> / <3,6> / <6,3> / <3,3>; -1 = automatic) and its XCD-aware
  * workgroup order (0 / 1, -1 = automatic) */
 void icm_debug_force_conv_cfg(int idx);
 /* pointwise (1x1 stride-1, Cin % 8 == 0) convolutions: -1 = automatic (the barrier-free direct-operand kernel when the
