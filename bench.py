@@ -58,7 +58,7 @@ def make_workload(model_name, dev, rank=0, group=None, batch=BATCH_PER_GPU):
 
 def family_of(label):
     if label.startswith("wgrad"):
-        return "wgrad_kernel + wgrad_reduce_kernel (weight gradients)"
+        return "wgrad_* kernels + wgrad_reduce_kernel (weight gradients)"
     if label.startswith("winattn"):
         return "winattn kernels (window attention core)"
     if label.startswith("pack"):

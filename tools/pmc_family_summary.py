@@ -5,9 +5,9 @@ import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_pmc_family.json")
 WHAT = {
-    "wg5": ("wgrad", "wgrad_kernel<2, 1, 7>", "wgrad 5x5 s2 192->192 on [16,192,128,128] (g_a.2 / g_s.6)",
+    "wg5": ("wgrad", "wgrad_", "wgrad 5x5 s2 192->192 on [16,192,128,128] (g_a.2 / g_s.6)",
             4 * (16 * 192 * 128 * 128 + 16 * 192 * 64 * 64 + 192 * 192 * 25), 2.0 * 16 * 192 * 192 * 25 * 64 * 64),
-    "wg1": ("wgrad_1x1", "wgrad_t33_kernel<6, 6, 2, 2", "wgrad 1x1 192->192 on [16,192,64,64]",
+    "wg1": ("wgrad_1x1", "wgrad_", "wgrad 1x1 192->192 on [16,192,64,64]",
             4 * (2 * 16 * 192 * 64 * 64 + 192 * 192), 2.0 * 16 * 192 * 192 * 64 * 64),
     "conv": ("conv", "conv_igemm_kernel", "g_a.2 forward conv5x5 s2 192->192 on [16,192,128,128]",
              4 * (16 * 192 * 128 * 128 + 16 * 192 * 64 * 64 + 192 * 192 * 25), 2.0 * 16 * 192 * 192 * 25 * 64 * 64),
@@ -21,7 +21,7 @@ for tag, (key, kmatch, workload, alg, flop) in WHAT.items():
         for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
             acc, cnt = {}, {}
             for r in csv.DictReader(open(f)):
-                if kmatch not in r["Kernel_Name"]:
+                if kmatch not in r["Kernel_Name"] or "reduce" in r["Kernel_Name"]:
                     continue
                 kname = r["Kernel_Name"]
                 c = r["Counter_Name"]
@@ -31,7 +31,7 @@ for tag, (key, kmatch, workload, alg, flop) in WHAT.items():
                 counters[c] = acc[c] / cnt[c]
         for f in glob.glob(os.path.join(d, "*", "*kernel_trace.csv")):
             for r in csv.DictReader(open(f)):
-                if kmatch in r["Kernel_Name"]:
+                if kmatch in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"]:
                     durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     if not counters:
         continue
