@@ -543,16 +543,17 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     bg = bg1;
   }
   const KernelCfg& c = kCfgs[best];
-  // Latency-bound launches (few workgroups whatever the tiling): the 8-wave K-split kernel (conv_ks8.hip).  Needs
-  // stride-1 sampling, no operand activation, the GDN / AXPY2 epilogues excluded (they belong to pointwise launches),
-  // and the step table in one VGPR (ckm * ntaps <= 64, as here).  OFF by default: measured on the training step it wins
-  // on the deep-K, wide-output chain layers (224 -> 176 @16x16: 60 -> 51 us, 480 -> 224: 116 -> 100 us) but loses on
-  // narrow outputs (64 -> 32: 17 -> 29 us), tiny maps and the 32x32 transposed 5x5 classes -- 338.5 -> 334.0 img/s over
-  // the whole step (same-box A/B); ICM_CONV_KS8=1 reproduces it, the parity tests force it (cfg 100 / 101).
+  // Latency-bound launches: the 8-wave K-split kernel (conv_ks8.hip).  Needs stride-1 sampling, no operand activation,
+  // the GDN / AXPY2 epilogues excluded (they belong to pointwise launches), and the step table in one VGPR
+  // (ckm * ntaps <= 64, as here).  It runs one workgroup per CU, so it is taken only when its grid is ONE nearly full
+  // round of the chip (160..256 workgroups): there it cuts the critical path of the serial slice-chain layers by ~15 %
+  // (224 -> 176 @16x16: 60 -> 51 us, 480 -> 224: 116 -> 100 us); applied to every small launch it lost 1.3 % on the
+  // step (narrow outputs 64 -> 32: 17 -> 29 us, half-empty grids, second-round tails; same-box A/B).
   int ks8_tco = 0;
   {
-    static const int ks8_on = getenv("ICM_CONV_KS8") ? atoi(getenv("ICM_CONV_KS8")) : 0;
-    static const long long ks8_max = getenv("ICM_CONV_KS8_MAXWG") ? atoll(getenv("ICM_CONV_KS8_MAXWG")) : 768;
+    static const int ks8_on = getenv("ICM_CONV_KS8") ? atoi(getenv("ICM_CONV_KS8")) : 1;
+    static const long long ks8_max = getenv("ICM_CONV_KS8_MAXWG") ? atoll(getenv("ICM_CONV_KS8_MAXWG")) : 256;
+    static const long long ks8_min = getenv("ICM_CONV_KS8_MINWG") ? atoll(getenv("ICM_CONV_KS8_MINWG")) : 160;
     const bool epi_ok = a.epi == ICM_EPI_NONE || a.epi == ICM_EPI_RES || a.epi == ICM_EPI_RES_GELU ||
                         a.epi == ICM_EPI_MUL_DGELU || a.epi == ICM_EPI_LRP || a.epi == ICM_EPI_RES_MUL_DGELU;
     if ((ks8_on && g_force_cfg < 0 || g_force_cfg == 100 || g_force_cfg == 101) && S_in == 1 && ntaps > 1 &&
@@ -568,7 +569,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
       const long long blocks = (long long)cdiv(ncot, tco) * g.tiles_x * g.tiles_y * g.tiles_n * ngroups;
       const bool fits = g.lds_bytes <= 160 * 1024 && (1 << g.lgTI) * g.PH * g.PW <= ICM_MAXJ * 64 && g.PWrow == g.PW &&
                         g.PP == g.PH * g.PW;
-      if (fits && (g_force_cfg >= 100 || blocks <= ks8_max)) {
+      if (fits && (g_force_cfg >= 100 || (blocks <= ks8_max && blocks >= ks8_min && tco == 2))) {
         ks8_tco = tco;
         bg = g;
       }
