@@ -63,7 +63,7 @@ def family_of(label):
         return "winattn kernels (window attention core)"
     if label.startswith("pack"):
         return "pack_weights kernels"
-    return "conv_igemm_kernel + conv1x1_kernel (forward + input gradients)"
+    return "conv_igemm_kernel + conv1x1_kernel + conv_ks8_kernel (forward + input gradients)"
 
 
 def shape_table(run_step, top=24):

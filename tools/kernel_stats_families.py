@@ -9,9 +9,9 @@ fam = {}
 for r in rows:
     n, t, c = r["Name"], float(r["TotalDurationNs"]) / 1e6, int(r["Calls"])
     if "wgrad" in n:
-        k = "wgrad_kernel + wgrad_reduce_kernel"
-    elif "conv_igemm" in n or "conv1x1" in n:
-        k = "conv_igemm_kernel + conv1x1_kernel"
+        k = "wgrad_* kernels + wgrad_reduce_kernel"
+    elif "conv_igemm" in n or "conv1x1" in n or "conv_ks8" in n:
+        k = "conv_igemm_kernel + conv1x1_kernel + conv_ks8_kernel"
     elif "winattn" in n:
         k = "winattn kernels"
     elif "pack_weights" in n:
