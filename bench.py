@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shape-table", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="train steps replayed from a captured hipGraph "
+                    "(Trainer.step_graphed; single GPU): reported as an extra line")
     ap.add_argument("--fwd-only", action="store_true", help="time eval-mode forward only (reported separately)")
     ap.add_argument("--model", default="cnn", choices=["cnn", "stf", "stf6"], help="cnn = BASELINE.json headline (default); "
                     "stf = configs[3], stf6 = the zigzag variant (SURVEY 8 f3): reported as extra lines")
@@ -194,7 +196,7 @@ def main():
             {"cnn": wacnn_forward, "stf": stf_forward, "stf6": stf6_forward}[args.model](
                 E.Tape(need_grad=False, packed_cache=packed), tr.params(), x)
             return None
-        return tr.step(x)
+        return tr.step_graphed(x) if args.graph else tr.step(x)
 
     first = None
     for i in range(args.warmup):
@@ -253,6 +255,8 @@ def main():
                               "unit": "TFLOP/s", "frac": ips / world * gflop / 1e3 / PEAK_F32_MFMA_TFLOPS,
                               "algorithmic_gflop_per_image": gflop},
         }
+        if args.graph:
+            line["config"]["workload"] += " [hipGraph replay: Trainer.step_graphed]"
         if first is not None:
             line["first_step"] = {"bpp": first[0], "mse": first[1], "loss": first[2], "aux": first[6]}
         if last is not None:

@@ -618,7 +618,12 @@ __global__ __launch_bounds__(256) void sqnorm_finish_kernel(const float* ws, int
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float step_size, float b1, float b2, float omb1,
-                            float omb2, float eps, float bc2_sqrt, const float* sqnorm, float max_norm, float gscale) {
+                            float omb2, float eps, float bc2_sqrt, const float* sqnorm, float max_norm, float gscale,
+                            const float* __restrict__ hyper) {
+  if (hyper) {   // step-dependent scalars from device memory (hipGraph replay: kernel arguments are frozen at capture)
+    step_size = hyper[0];
+    bc2_sqrt = hyper[1];
+  }
   float coef = gscale;
   if (sqnorm) {
     const float total = sqrtf(*sqnorm) * gscale;
@@ -924,7 +929,16 @@ int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
   const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, (float)(lr / bc1),
                      (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)bc2s,
-                     sqnorm, max_norm, gscale);
+                     sqnorm, max_norm, gscale, (const float*)nullptr);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps,
+                        const float* hyper, const float* sqnorm, float max_norm, float gscale, void* stream) {
+  if (!p || !g || !m || !v || !hyper || n <= 0) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, 0.0f, (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, 1.0f, sqnorm, max_norm, gscale,
+                     hyper);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -70,7 +70,7 @@ SYMBOLS = [
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_layernorm_fwd", "icm_layernorm_bwd", "icm_space_to_depth2",
     "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
-    "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_fill",
+    "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_adam_step_hyper", "icm_fill",
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_conv1x1",
     "icm_debug_force_wgrad_cfg",
     "icm_debug_force_winattn_valu",
@@ -149,6 +149,7 @@ def lib():
         L.icm_rd_loss_bwd.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, f32, vp, vp, vp, vp]
         L.icm_grad_sqnorm.argtypes = [vp, i64, vp, vp, vp]
         L.icm_adam_step.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp, f32, f32, vp]
+        L.icm_adam_step_hyper.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, vp, vp, f32, f32, vp]
         L.icm_fill.argtypes = [vp, i64, f32, vp]
         # entropy coding (host) + its device-side table / symbol kernels
         i32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)

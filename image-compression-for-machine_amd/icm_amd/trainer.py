@@ -16,6 +16,7 @@ with the clip coefficient computed on the device (no host sync anywhere in the s
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -176,6 +177,70 @@ class Trainer:
     def params(self) -> Dict[str, torch.Tensor]:
         return self.flat.views
 
+    def step_graphed(self, x: torch.Tensor) -> torch.Tensor:
+        """step(x) replayed from a captured hipGraph: one host call per iteration instead of ~1 000 (cnn) to ~8 000
+        (stf6) launches issued through Python.  The first two calls per input shape run eagerly (they record the
+        weight-packing sequence and set kernel attributes); the third captures.  What changes from step to step lives
+        in device memory the graph reads: the input batch, the quantisation noise and DropPath scales (drawn outside the
+        graph from this rank's generator, in the same order as step() draws them) and Adam's step-dependent scalars
+        (icm_adam_step_hyper) -- so a replayed step equals the eager step bit for bit.  Single process only (the RCCL
+        reductions are not captured); the side stream of the weight gradients is forked and joined inside the capture."""
+        if self.world > 1:
+            raise RuntimeError("step_graphed: single-process training only")
+        key = tuple(x.shape)
+        g = getattr(self, "_graph", None)
+        if g is None or g["key"] != key:
+            if getattr(self, "_graph_warm", None) != key:
+                self._graph_warm, self._graph_warm_n = key, 0
+            if self._graph_warm_n < 2:
+                self._graph_warm_n += 1
+                return self.step(x)
+            g = self._capture(x)
+        B, _, H, W = x.shape
+        dev = self.device
+        self.step_no += 1
+        g["hyper"][0].copy_(torch.tensor(_adam_hyper(self.lr, self.step_no), dtype=torch.float32))
+        g["hyper"][1].copy_(torch.tensor(_adam_hyper(self.aux_lr, self.step_no), dtype=torch.float32))
+        # the same draws, in the same order, as step() makes (z noise, y noise, then the DropPath scales)
+        g["nz"].copy_(torch.rand(g["nz"].shape, dtype=torch.float32, device=dev, generator=self.gen) - 0.5)
+        g["ny"].copy_((torch.rand((B, self.lat_ch, H // 16, W // 16), dtype=torch.float32, device=dev,
+                                  generator=self.gen) - 0.5).reshape(g["ny"].shape))
+        if g["drops"] is not None:
+            fresh = self.model.draw_drops(B, dev, generator=self.gen)
+            for k, v in g["drops"].items():
+                v.copy_(fresh[k])
+        g["x"].copy_(x)
+        g["graph"].replay()
+        E.bump_weight_generation()
+        return self.scal
+
+    def _capture(self, x: torch.Tensor):
+        dev = self.device
+        B, _, H, W = x.shape
+        side = self.side
+        if os.environ.get("ICM_GRAPH_SIDE", "1") == "0":
+            self.side = None                       # weight gradients on the capture stream
+        ny_shape = (B, 24, 64, H // 32, W // 32) if self.is_stf6 else (B, self.lat_ch, H // 16, W // 16)
+        g = {"key": tuple(x.shape), "x": x.detach().clone().contiguous(),
+             "nz": torch.zeros((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev),
+             "ny": torch.zeros(ny_shape, dtype=torch.float32, device=dev),
+             "drops": None,
+             "hyper": (torch.ones(2, dtype=torch.float32, device=dev), torch.ones(2, dtype=torch.float32, device=dev))}
+        if self.is_stf:
+            gen_state = self.gen.get_state()       # shapes / keys only: the capture must not consume random numbers
+            g["drops"] = {k: v.clone() for k, v in self.model.draw_drops(B, dev, generator=self.gen).items()}
+            self.gen.set_state(gen_state)
+        step_no = self.step_no
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.step(g["x"], noise={"z": g["nz"], "y": g["ny"]}, drops=g["drops"], _hyper=g["hyper"])
+        self.step_no = step_no                      # nothing ran during capture
+        self.side = side
+        g["graph"] = graph
+        self._graph = g
+        return g
+
     def optimizer_state(self):
         """(optimizer, aux_optimizer) checkpoint entries (train.py:521-523): Adam moments per parameter NAME (independent
         of the flat-buffer layout), the step count and the learning rates"""
@@ -213,13 +278,16 @@ class Trainer:
             unpack(f.aux, f.am, f.av, aux, False)
             self.aux_lr = float(aux.get("lr", self.aux_lr))
 
-    def step(self, x: torch.Tensor, noise: Optional[dict] = None, drops: Optional[dict] = None) -> torch.Tensor:
+    def step(self, x: torch.Tensor, noise: Optional[dict] = None, drops: Optional[dict] = None,
+             _hyper: Optional[tuple] = None) -> torch.Tensor:
         """one training iteration on this rank's shard x [B,3,H,W]; returns the device tensor
-        [bpp, mse, loss, sumlog_y, sumlog_z, grad_sqnorm, aux_loss, -] (no host sync)."""
+        [bpp, mse, loss, sumlog_y, sumlog_z, grad_sqnorm, aux_loss, -] (no host sync).
+        _hyper (step_graphed only): device tensors holding Adam's step-dependent scalars for the two optimisers."""
         f, dev = self.flat, self.device
         st = L.stream()
         lib = L.lib()
-        self.step_no += 1
+        if _hyper is None:
+            self.step_no += 1
         B, _, H, W = x.shape
         if noise is None:
             nz = torch.rand((B, 192, H // 64, W // 64), dtype=torch.float32, device=dev, generator=self.gen) - 0.5
@@ -294,16 +362,31 @@ class Trainer:
         gscale = 1.0 / self.world
         sq = self.scal[5:6]
         check(lib.icm_grad_sqnorm(ptr(f.g), f.n_main, ptr(sq), ptr(self.red_ws), st), "grad_sqnorm")
-        check(lib.icm_adam_step(ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.v), f.n_main, self.lr, 0.9, 0.999, 1e-8,
-                                self.step_no, ptr(sq) if self.clip > 0 else 0, float(self.clip), gscale, st), "adam")
+        if _hyper is None:
+            check(lib.icm_adam_step(ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.v), f.n_main, self.lr, 0.9, 0.999, 1e-8,
+                                    self.step_no, ptr(sq) if self.clip > 0 else 0, float(self.clip), gscale, st), "adam")
+        else:
+            check(lib.icm_adam_step_hyper(ptr(f.p), ptr(f.g), ptr(f.m), ptr(f.v), f.n_main, 0.9, 0.999, 1e-8,
+                                          ptr(_hyper[0]), ptr(sq) if self.clip > 0 else 0, float(self.clip), gscale, st),
+                  "adam")
         # ---- aux loss on the UPDATED bottleneck weights, gradient to quantiles only (train.py:212-214)
         prm = E._eb_params(P, "entropy_bottleneck")
         t = math_target()
         check(lib.icm_eb_aux_loss(C.byref(prm), ptr(self.scal[6:7]), ptr(f.ag), 192, t, st), "eb_aux")
-        check(lib.icm_adam_step(ptr(f.ap), ptr(f.ag), ptr(f.am), ptr(f.av), f.ap.numel(), self.aux_lr, 0.9, 0.999, 1e-8,
-                                self.step_no, 0, 0.0, 1.0, st), "adam_aux")
+        if _hyper is None:
+            check(lib.icm_adam_step(ptr(f.ap), ptr(f.ag), ptr(f.am), ptr(f.av), f.ap.numel(), self.aux_lr, 0.9, 0.999,
+                                    1e-8, self.step_no, 0, 0.0, 1.0, st), "adam_aux")
+        else:
+            check(lib.icm_adam_step_hyper(ptr(f.ap), ptr(f.ag), ptr(f.am), ptr(f.av), f.ap.numel(), 0.9, 0.999, 1e-8,
+                                          ptr(_hyper[1]), 0, 0.0, 1.0, st), "adam_aux")
         E.bump_weight_generation()   # packed-weight caches keyed before this step are stale now
         return self.scal
+
+
+def _adam_hyper(lr: float, step: int):
+    """the two step-dependent scalars of icm_adam_step, formed in double like torch.optim.Adam forms them"""
+    import math
+    return [lr / (1.0 - 0.9 ** step), math.sqrt(1.0 - 0.999 ** step)]
 
 
 def _broadcast0(t: torch.Tensor, group=None):

@@ -310,6 +310,11 @@ int icm_grad_sqnorm(const float* g, int64_t n, float* out, float* ws, void* stre
  * g is scaled by gscale (1/world_size) then coef; torch.optim.Adam defaults semantics. */
 int icm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, int step, const float* sqnorm, float max_norm, float gscale, void* stream);
+/* the same update with the two step-dependent scalars read from DEVICE memory -- hyper[0] = lr / (1 - beta1^step),
+ * hyper[1] = sqrt(1 - beta2^step), formed by the caller in double and rounded to f32 exactly as icm_adam_step forms
+ * them -- so that a captured hipGraph of the training step can be replayed (kernel arguments are frozen at capture) */
+int icm_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, double beta1, double beta2, double eps,
+                        const float* hyper, const float* sqnorm, float max_norm, float gscale, void* stream);
 int icm_fill(float* p, int64_t n, float v, void* stream);
 /* x_hat.clamp_(0, 1) of decompress() (cnn.py:330) */
 int icm_clamp(float* p, int64_t n, float lo, float hi, void* stream);

@@ -72,3 +72,29 @@ def test_graphed_forward_batch1_speedup():
     print(f"cnn eval forward, batch 1, 256x256: eager {t_eager:.2f} ms, graph replay {t_graph:.2f} ms "
           f"({t_eager / t_graph:.2f}x)")
     assert t_graph < t_eager
+
+
+@pytest.mark.parametrize("name,shape", [("cnn", (2, 3, 64, 64)), ("stf", (2, 3, 64, 64)), ("stf6", (1, 3, 128, 128))])
+def test_step_graphed_equals_eager_steps(name, shape):
+    """Trainer.step_graphed (two eager warm-up steps, then hipGraph replays with noise / DropPath scales / Adam scalars
+    fed through device memory) leaves the SAME parameters as the same number of eager steps, bit for bit"""
+    from icm_amd.trainer import Trainer
+    from icm_amd.zoo import models
+    sd = {"cnn": W.make_wacnn_state_dict, "stf": W.make_stf_state_dict, "stf6": W.make_stf6_state_dict}[name]()
+    xs = [W._u(f"tg.{name}.x{i}", shape, 0.0, 1.0).cuda() for i in range(5)]
+    outs = []
+    for graphed in (False, True):
+        net = models[name]()
+        net.load_state_dict(sd)
+        tr = Trainer(net, device="cuda:0", seed=5)
+        losses = []
+        for x in xs:
+            s = tr.step_graphed(x) if graphed else tr.step(x)
+            losses.append(s.clone())
+        torch.cuda.synchronize()
+        outs.append((torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}))
+        if graphed:
+            assert tr.step_no == 5 and tr._graph is not None
+    assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0][:, 2], outs[1][0][:, 2])
+    for k, v in outs[0][1].items():
+        assert torch.equal(v, outs[1][1][k]), k
