@@ -36,6 +36,11 @@ SHAPES = [
     ("3x3 160->160 @16 x6", 16, 160, 16, 16, 160, 3, 1, 6),
     ("3x3 320->320 @16", 16, 320, 16, 16, 320, 3, 1, 1),
     ("3x3 576->224 @16 x12", 16, 576, 16, 16, 224, 3, 1, 12),
+    ("3x3 48->3 @256 (stf end_conv.2)", 16, 48, 256, 256, 3, 3, 1, 1),
+    ("5x5s1 48->192 @128 (stf end_conv.0)", 16, 48, 128, 128, 192, 5, 1, 1),
+    ("1x1 48->144 @128 (stf qkv)", 16, 48, 128, 128, 144, 1, 1, 1),
+    ("1x1 48->48 @128 (stf proj)", 16, 48, 128, 128, 48, 1, 1, 1),
+    ("1x1 192->48 @128 (stf fc2)", 16, 192, 128, 128, 48, 1, 1, 1),
     # virtual-GELU inputs (what most 3x3 / RU layers see in the step): name ends with "gelu"
     ("3x3 96->96 @64 x6 gelu", 16, 96, 64, 64, 96, 3, 1, 6),
     ("3x3 224->176 @16 x11 gelu", 16, 224, 16, 16, 176, 3, 1, 11),
