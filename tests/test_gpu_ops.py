@@ -790,5 +790,20 @@ def test_conv_ks8_fused_neighbours():
         test_attention_gate_vs_oracle(320, 4, 2, 8)
         lib.icm_debug_force_conv_cfg(101)
         test_conv_group_shared_input_and_lrp_tail_vs_singles()
+        # fused PixelShuffle store (subpel_conv3x3 of the hyper synthesis) and the materialised-GELU second output
+        from icm_amd import engine as E
+        from icm_amd.engine import VT
+        x = U("ks8.ps.x", (2, 40, 8, 12), -1.0, 1.0)
+        w = U("ks8.ps.w", (96, 40, 3, 3), -0.2, 0.2)
+        b = U("ks8.ps.b", (96,), -0.3, 0.3)
+        ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
+        min_px, E._MAT_MIN_PIXELS = E._MAT_MIN_PIXELS, 0      # materialise even this small launch
+        for cfg in (100, 101):
+            lib.icm_debug_force_conv_cfg(cfg)
+            tape = E.Tape(need_grad=False)
+            y = E.conv2d(tape, VT(x.to(dev())), w.to(dev()), b.to(dev()), pad=1, pixel_shuffle=2, act_out=True)
+            close(y, ref, what=f"pixel-shuffle store cfg {cfg}")
+            close(tape.mat[E._key(y)], F.gelu(ref), what=f"materialised gelu cfg {cfg}")
+        E._MAT_MIN_PIXELS = min_px
     finally:
         lib.icm_debug_force_conv_cfg(-1)
