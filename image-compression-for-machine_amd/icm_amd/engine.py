@@ -1151,7 +1151,7 @@ def zigzag_reverse(tape, z, num_slices: int, nH: int = 2, nW: int = 2) -> torch.
 class _TapeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, nstop, *tensors):
-        tape = Tape(need_grad=True)
+        tape = Tape(need_grad=True, packed_cache=runner.packed_cache)
         outs = runner(tape, *tensors)
         ctx.tape, ctx.tensors, ctx.outs = tape, tensors, outs
         return tuple(outs)
@@ -1171,11 +1171,12 @@ class _TapeFn(torch.autograd.Function):
         return (None, None, *res)
 
 
-def tape_function(runner, tensors: Sequence[torch.Tensor]):
-    """Run ``runner(tape, *tensors) -> tuple(outputs)`` as ONE autograd node whose backward is the tape."""
+def tape_function(runner, tensors: Sequence[torch.Tensor], packed_cache: Optional[dict] = None):
+    """Run ``runner(tape, *tensors) -> tuple(outputs)`` as ONE autograd node whose backward is the tape.
+    packed_cache: see Tape (eval-mode calls of a module keep their MFMA-order weight copies between calls)."""
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        return _TapeFn.apply(_Needs(runner, tensors), 0, *tensors)
-    tape = Tape(need_grad=False)
+        return _TapeFn.apply(_Needs(runner, tensors, packed_cache), 0, *tensors)
+    tape = Tape(need_grad=False, packed_cache=packed_cache)
     with torch.no_grad():
         return tuple(runner(tape, *[t.detach() for t in tensors]))
 
@@ -1183,8 +1184,9 @@ def tape_function(runner, tensors: Sequence[torch.Tensor]):
 class _Needs:
     """callable wrapper that marks non-differentiable inputs as stopped before running"""
 
-    def __init__(self, runner, tensors):
+    def __init__(self, runner, tensors, packed_cache=None):
         self.runner = runner
+        self.packed_cache = packed_cache
         self.flags = [bool(t.requires_grad) for t in tensors]
 
     def __call__(self, tape, *ts):

@@ -5,8 +5,9 @@ at small batch sizes each kernel runs for a few microseconds and the step is bou
 Python.  ``GraphedForward`` captures the whole launch sequence of one ``model(x)`` call in eval mode into a HIP graph
 (``torch.cuda.CUDAGraph``: every ``icm_*`` entry point enqueues on the stream it is handed, never allocates or
 synchronises, so the sequence is capturable as is) and replays it for later inputs of the same shape: one host call per
-forward.  The weight-packing launches are part of the graph, so updated parameters (training between evaluations,
-``load_state_dict`` in place) are picked up by the next replay.
+forward.  The graph reads the model's eval-mode packed weight copies (``CompressionModel._pack_cache``); when a parameter
+changes (training between evaluations, ``load_state_dict``) that cache is rebuilt and the graph is captured again on the
+next call, so replays never see stale weights.
 
     fwd = GraphedForward(net)            # net.eval()
     out = fwd(x)                         # first call per input shape: warm-up + capture; then replay
@@ -37,7 +38,11 @@ class GraphedForward:
         if not x.is_cuda or x.dtype != torch.float32:
             raise ValueError("GraphedForward expects a float32 device tensor")
         k = self._key(x)
+        self.model._pack_cache()                      # refreshes the packed-weight cache if a parameter changed
+        sig = getattr(self.model, "_pack_sig", None)
         ent = self._graphs.get(k)
+        if ent is not None and ent[3] != sig:         # captured against packed copies that no longer exist
+            ent = None
         if ent is None:
             static_x = x.detach().clone().contiguous()
             side = torch.cuda.Stream(device=x.device)
@@ -49,9 +54,9 @@ class GraphedForward:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.model(static_x)
-            ent = (g, static_x, out)
+            ent = (g, static_x, out, getattr(self.model, "_pack_sig", None))
             self._graphs[k] = ent
-        g, static_x, out = ent
+        g, static_x, out, _ = ent
         static_x.copy_(x)
         g.replay()
         return out

@@ -34,6 +34,18 @@ class CompressionModel(nn.Module):
         super().__init__()
         # the reference calls _initialize_weights() here, before any sub-module exists: a no-op
 
+    def _pack_cache(self) -> Optional[dict]:
+        """eval mode: the MFMA-order weight copies are kept between calls (inference serving: packing 300 MB of weights
+        per call costs more than a batch-1 forward).  The cache is dropped whenever a parameter changed -- in place
+        through torch (version counters) or through the HIP optimiser (engine weight generation); train mode and
+        graph capture (icm_amd/graphs.py: the packing launches belong in the graph) do not use it."""
+        if self.training or getattr(self, "_eval_cache_off", False):
+            return None
+        sig = (E._weight_gen[0], sum(p._version for p in self.parameters()))
+        if getattr(self, "_pack_sig", None) != sig:
+            self._pack_eval, self._pack_sig = {}, sig
+        return self._pack_eval
+
     def aux_loss(self):
         return sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
 
@@ -686,7 +698,7 @@ class WACNN(CompressionModel):
         def runner(tape, xin, *ps):
             return wacnn_forward(tape, dict(zip(names, ps)), xin, nz, ny, ns, ms)
 
-        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
+        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params], self._pack_cache())
         return {"x_hat": _crop_eval_output(x_hat, pads), "likelihoods": {"y": y_lik, "z": z_lik}}
 
     @classmethod
@@ -704,14 +716,14 @@ class WACNN(CompressionModel):
         """cnn.py:210-266 -> {"strings": [[y_string], z_strings], "shape": z.shape[-2:]}"""
         _check_codec_input(x)
         P = self._params()
-        tape = E.Tape(need_grad=False)
+        tape = E.Tape(need_grad=False, packed_cache=self._pack_cache())
         return self._compress_latent(tape, P, wacnn_g_a(tape, P, x.contiguous()), _debug)
 
     @torch.no_grad()
     def decompress(self, strings, shape):
         """cnn.py:289-332 -> {"x_hat"} clamped to [0, 1]"""
         P = self._params()
-        tape = E.Tape(need_grad=False)
+        tape = E.Tape(need_grad=False, packed_cache=self._pack_cache())
         x_hat = wacnn_g_s(tape, P, self._decompress_latent(tape, P, strings, shape, 320))
         L.check(L.lib().icm_clamp(L.ptr(x_hat), x_hat.numel(), 0.0, 1.0, tape.st), "clamp")
         return {"x_hat": x_hat}
@@ -941,7 +953,7 @@ class SymmetricalTransFormer(CompressionModel):
         def runner(tape, xin, *ps):
             return stf_forward(tape, dict(zip(names, ps)), xin, nz, ny, drops, ns, ms, ws)
 
-        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
+        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params], self._pack_cache())
         return {"x_hat": _crop_eval_output(x_hat, pads), "likelihoods": {"y": y_lik, "z": z_lik}}
 
     @classmethod
@@ -959,13 +971,13 @@ class SymmetricalTransFormer(CompressionModel):
         """stf.py compress(): analysis transform, then the shared latent coder"""
         _check_codec_input(x)
         P = self._params()
-        tape = E.Tape(need_grad=False)
+        tape = E.Tape(need_grad=False, packed_cache=self._pack_cache())
         return self._compress_latent(tape, P, stf_analysis(tape, P, x.contiguous(), None, self.window_size), _debug)
 
     @torch.no_grad()
     def decompress(self, strings, shape):
         P = self._params()
-        tape = E.Tape(need_grad=False)
+        tape = E.Tape(need_grad=False, packed_cache=self._pack_cache())
         y_hat = self._decompress_latent(tape, P, strings, shape, 384)
         x_hat = stf_synthesis(tape, P, y_hat, None, self.window_size)
         L.check(L.lib().icm_clamp(L.ptr(x_hat), x_hat.numel(), 0.0, 1.0, tape.st), "clamp")
@@ -1056,7 +1068,7 @@ class SymmetricalTransFormer3(SymmetricalTransFormer):
         def runner(tape, xin, *ps):
             return stf6_forward(tape, dict(zip(names, ps)), xin, nz, ny, drops, ws)
 
-        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params])
+        x_hat, y_lik, z_lik = E.tape_function(runner, [x.contiguous(), *params], self._pack_cache())
         return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
 
     def update(self, scale_table=None, force=False):

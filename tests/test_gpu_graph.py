@@ -98,3 +98,36 @@ def test_step_graphed_equals_eager_steps(name, shape):
     assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0][:, 2], outs[1][0][:, 2])
     for k, v in outs[0][1].items():
         assert torch.equal(v, outs[1][1][k]), k
+
+
+def test_eval_pack_cache_follows_weight_updates():
+    """eval-mode module calls keep their packed weight copies between calls and drop them when a parameter changes,
+    whether through torch (version counter) or through the HIP trainer (engine weight generation)"""
+    from icm_amd import engine as E
+    from icm_amd.trainer import Trainer
+    from icm_amd.zoo import models
+    net = models["cnn"]()
+    net.load_state_dict(W.make_wacnn_state_dict())
+    net = net.cuda().eval()
+    x = W._u("pc.x", (1, 3, 64, 64), 0.0, 1.0).cuda()
+    with torch.no_grad():
+        a = net(x)["x_hat"].clone()
+        n_packed = len(net._pack_eval)
+        assert n_packed > 100
+        b = net(x)["x_hat"].clone()
+        assert torch.equal(a, b) and len(net._pack_eval) == n_packed          # second call: cache hits only
+        dict(net.named_parameters())["g_s.8.bias"].add_(0.5)                  # torch in-place update
+        c = net(x)["x_hat"].clone()
+        assert not torch.equal(a, c) and len(net._pack_eval) == n_packed      # dropped and rebuilt, not grown
+    net.train()
+    assert net._pack_cache() is None
+    tr = Trainer(net, device="cuda:0")
+    tr.step(torch.rand(1, 3, 64, 64, device="cuda"))
+    net.eval()
+    with torch.no_grad():
+        d = net(x)["x_hat"].clone()
+        ref = None
+        net._eval_cache_off = True
+        ref = net(x)["x_hat"].clone()
+        net._eval_cache_off = False
+    assert torch.equal(d, ref) and not torch.equal(d, c)                      # the step's update was picked up
