@@ -25,6 +25,8 @@ SHAPES = [
     ("3x3 96->96 @64 x6", 16, 96, 64, 64, 96, 3, 1, 6),
     ("5x5s2 192->192 @128", 16, 192, 128, 128, 192, 5, 2, 1),
     ("5x5s2 192->192 @64", 16, 192, 64, 64, 192, 5, 2, 1),
+    ("5x5s2 192->320 @32", 16, 192, 32, 32, 320, 5, 2, 1),
+    ("5x5s2 192->192 @32 (g_s.2 as wgrad)", 16, 192, 32, 32, 192, 5, 2, 1),
     ("3x3 480->224 @16 x10", 16, 480, 16, 16, 224, 3, 1, 10),
     ("3x3 224->176 @16 x11", 16, 224, 16, 16, 176, 3, 1, 11),
     ("3x3 128->64 @16 x10", 16, 128, 16, 16, 64, 3, 1, 10),
