@@ -145,6 +145,42 @@ def cpu_baseline(sd_cpu, threads, x_cpu):
                       f"{dt*1e3:.0f} ms/iter"}
 
 
+def timed(fn, warmup, steps):
+    """ms per call of fn(): warm-up calls, then `steps` calls bracketed by device synchronisation"""
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def roofline_of(ips, gflop_per_image):
+    tf = ips * gflop_per_image / 1e3
+    return {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / PEAK_F32_MFMA_TFLOPS, "algorithmic_gflop_per_image": gflop_per_image}
+
+
+def forward_bench(model_name, params, x, warmup=2, steps=10):
+    """eval-mode forward (cnn.py:141-189 / stf.py:582-645) on the resident batch x with the constant-weight packed
+    cache of the inference path: {value img/s, ms_per_step, roofline_step}"""
+    from icm_amd import engine as E
+    from icm_amd.models import stf6_forward, stf_forward, wacnn_forward
+    fwd = {"cnn": wacnn_forward, "stf": stf_forward, "stf6": stf6_forward}[model_name]
+    packed = {}
+    ms = timed(lambda: fwd(E.Tape(need_grad=False, packed_cache=packed), params, x), warmup, steps)
+    ips = x.shape[0] / ms * 1e3
+    gf = {"cnn": FWD_GFLOP_PER_IMG, "stf": 67.0}.get(model_name)
+    out = {"value": ips, "unit": "images/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+           "batch": int(x.shape[0])}
+    if gf is not None:
+        out["roofline_step"] = roofline_of(ips, gf)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +193,8 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="time eval-mode forward only (reported separately)")
     ap.add_argument("--model", default="cnn", choices=["cnn", "stf", "stf6"], help="cnn = BASELINE.json headline (default); "
                     "stf = configs[3], stf6 = the zigzag variant (SURVEY 8 f3): reported as extra lines")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and stf sub-objects of the default "
+                    "1-GPU cnn line")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
@@ -236,7 +274,7 @@ def main():
         if args.model == "stf":   # stf forward 33.498 GMAC = 67.0 GFLOP/image
             gflop = 67.0 if args.fwd_only else 3 * 67.0
         if args.model == "stf6":  # no survey figure: algorithmic FLOP of the GEMM / attention launches of the profiled step
-            gflop = (sum(v["gflop"] for v in fams.values()) / BATCH_PER_GPU) if fams else float("nan")
+            gflop = (sum(v["gflop"] for v in fams.values()) / BATCH_PER_GPU) if fams else None
         line = {
             "metric": {"cnn": "images/sec (256x256) cnn-hyperprior (WACNN) ",
                        "stf": "images/sec (256x256) stf (SymmetricalTransFormer) ",
@@ -251,9 +289,10 @@ def main():
                                      "aux Adam, clip 1.0" if not args.fwd_only else
                                      " eval forward, batch 16/GPU synthetic 256x256")),
                        "global_batch": world * BATCH_PER_GPU, "parallelism": f"dp{world}"},
-            "roofline_step": {"bound": "mfma", "achieved": ips / world * gflop / 1e3, "peak": PEAK_F32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ips / world * gflop / 1e3 / PEAK_F32_MFMA_TFLOPS,
-                              "algorithmic_gflop_per_image": gflop},
+            # what the collective layer saw (RCCL = backend "nccl" on ROCm); None / 1 for a single process
+            "dist": {"backend": dist.get_backend() if world > 1 else None,
+                     "world_size": dist.get_world_size() if world > 1 else 1},
+            "roofline_step": roofline_of(ips / world, gflop) if gflop is not None else None,
         }
         if args.graph:
             line["config"]["workload"] += " [hipGraph replay: Trainer.step_graphed]"
@@ -278,9 +317,23 @@ def main():
             line["roofline_families"] = fams
             line["roofline_shapes"] = rows
             line["profiled_step"] = {"kernel_ms_sum": round(ktot, 3), "wall_ms": round(wall, 3)}
+        # ---- sub-objects of the default driver line (1 GPU, cnn train step): the eval forward of the same model on the
+        # same batch (the north-star target is stated on the forward) and the stf model's train step + forward
+        if world == 1 and args.model == "cnn" and not args.fwd_only and not args.graph and not args.no_extras:
+            line["forward"] = forward_bench("cnn", tr.params(), x)
+            try:
+                tr2, x2, _ = make_workload("stf", dev, rank)
+                ms2 = timed(lambda: tr2.step(x2), 3, 8)
+                ips2 = BATCH_PER_GPU / ms2 * 1e3
+                line["stf"] = {"train": {"value": ips2, "unit": "images/s", "ms_per_step": ms2, "steps": 8, "warmup": 3,
+                                         "batch": BATCH_PER_GPU, "roofline_step": roofline_of(ips2, 3 * 67.0)},
+                               "forward": forward_bench("stf", tr2.params(), x2)}
+                del tr2, x2
+            except Exception as e:   # the headline line must survive a failure of the extra model
+                line["stf"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and args.model == "cnn":
             line["cpu_baseline"] = cpu_baseline(sd_cpu, min(os.cpu_count() or 1, 16), x.cpu())
-        print(json.dumps(line))
+        print(json.dumps(line, allow_nan=False))
     if world > 1:
         dist.destroy_process_group()
 

@@ -1006,8 +1006,10 @@ def eb_likelihood(tape, z, P, p="entropy_bottleneck", noise=None, lik_bound=1e-9
     if tape.need_grad:
         def bwd():
             dl = tape.grad_of(lik)
-            if dl is None:
+            if dl is None and (zt is None or tape.grad_of(zt) is None):
                 return
+            if dl is None:
+                dl = torch.zeros_like(lik)
             dl = dl if dl.is_contiguous() else dl.contiguous()
             g = L.EbGrads()
             for i in range(5):
@@ -1030,6 +1032,17 @@ def eb_likelihood(tape, z, P, p="entropy_bottleneck", noise=None, lik_bound=1e-9
                 dz, acc = torch.empty_like(zc), 0
             check(L.lib().icm_eb_likelihood_bwd(ptr(zc), ptr(noise), C.byref(prm), ptr(dl), ptr(dz), C.byref(g), N, Cc,
                                                 HW, lik_bound, acc, tape.st), "eb_bwd")
+            # the returned outputs z~ = quantize(z, "noise" | "dequantize", medians) carry a gradient too
+            # (entropy_models.py:126-150,468-472): identity to z in noise mode; in dequantize mode zero to z (round) and
+            # one to the medians (added back after the round)
+            dzt = tape.grad_of(zt) if zt is not None else None
+            if dzt is not None:
+                if noise is not None:
+                    accumulate(tape, z, dzt.contiguous())
+                elif dmed is not None:
+                    dm2 = torch.empty(Cc, dtype=torch.float32, device=z.device)
+                    channel_sum(tape, dzt.contiguous().view(N, Cc, -1, 1), dm2, 0)
+                    check(L.lib().icm_add_grad(ptr(dm2), 0, ptr(dmed), Cc, 1, tape.st), "add_grad")
             if dmed is not None and tape.wants(P[f"{p}.quantiles"]):
                 gq, accq = tape.grad_for_write(P[f"{p}.quantiles"])
                 if not accq:

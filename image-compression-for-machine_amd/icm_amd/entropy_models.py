@@ -148,7 +148,10 @@ class EntropyModel(nn.Module):
     def _tables(self):
         """host copies of the coder tables, cached until the buffers change"""
         from .ans import _Tables
-        key = (self._quantized_cdf.data_ptr(), self._quantized_cdf._version, tuple(self._quantized_cdf.shape))
+        # keyed on a counter that update() / load_state_dict() bump, plus the buffers' identity: the caching allocator can
+        # hand a freed block back, so (data_ptr, _version, shape) alone would serve stale tables after update(force=True)
+        key = (getattr(self, "_tab_gen", 0), self._quantized_cdf.data_ptr(), self._quantized_cdf._version,
+               tuple(self._quantized_cdf.shape), self._offset.data_ptr(), self._cdf_length.data_ptr())
         if getattr(self, "_tab_key", None) != key:
             self._tab = _Tables(self._quantized_cdf.detach().cpu().numpy(), self._cdf_length.detach().cpu().numpy(),
                                 self._offset.detach().cpu().numpy())
@@ -199,6 +202,16 @@ class EntropyModel(nn.Module):
             out[i] = dec.decode_stream_np(np.ascontiguousarray(idx[i].reshape(-1)), t).reshape(idx[i].shape)
         sym = torch.from_numpy(out).to(self._quantized_cdf.device)
         return self.dequantize(sym, means)
+
+    def _invalidate_tables(self):
+        """drop the host copies of the coder tables (called by every update() and by load_state_dict)"""
+        self._tab_gen = getattr(self, "_tab_gen", 0) + 1
+        self._tab_key = None
+        self._tab = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._invalidate_tables()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def update(self, *a, **k):
         raise NotImplementedError()
@@ -268,6 +281,7 @@ class EntropyBottleneck(EntropyModel):
         self._offset = offset
         self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length)
         self._cdf_length = pmf_length + 2
+        self._invalidate_tables()
         return True
 
     def _pmf_tables(self):
@@ -333,6 +347,33 @@ class _EbAux(torch.autograd.Function):
         return None, dq * g
 
 
+class _QuantizeOut(torch.autograd.Function):
+    """EntropyModel.quantize in its two differentiable modes (entropy_models.py:126-150) on the HIP kernels:
+    noise given -> inputs + noise (identity gradient to inputs); else round(inputs - means) + means, whose gradient is
+    zero for inputs (torch.round) and one for means (added back after the round)."""
+
+    @staticmethod
+    def forward(ctx, mod, inputs, means, noise):
+        ctx.noise_mode = noise is not None
+        ctx.bshape = means.shape
+        x = inputs.to(torch.float32).contiguous()
+        if noise is not None:
+            out = x.clone()
+            check(L.lib().icm_add_grad(ptr(noise.contiguous()), 0, ptr(out), out.numel(), 1, L.stream()), "add noise")
+            return out
+        with torch.no_grad():
+            return mod.quantize(x, "dequantize", means)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.noise_mode:
+            return None, g, None, None
+        gm = g
+        if tuple(ctx.bshape) != tuple(g.shape):   # broadcast means: sum the gradient over the broadcast dims
+            gm = g.sum_to_size(ctx.bshape)
+        return None, None, gm, None
+
+
 class GaussianConditional(EntropyModel):
     """entropy_models.py:525-659.  forward(inputs, scales, means) -> (outputs, likelihood)."""
 
@@ -380,6 +421,7 @@ class GaussianConditional(EntropyModel):
         self._quantized_cdf = self._pmf_to_cdf(pmf, tail, pmf_length, max_length)
         self._offset = offset
         self._cdf_length = pmf_length + 2
+        self._invalidate_tables()
 
     def _pmf_tables(self):
         """device side of update(): (offset [ns] int32, pmf [ns, L], tail_mass [ns, 1], pmf_length [ns] int32, L)"""
@@ -437,6 +479,7 @@ class GaussianConditional(EntropyModel):
             E.gc_likelihood_ste(tape, y, mu, sc, noise, lik, None, None, sb, lb)
             return (lik,)
         (lik,) = E.tape_function(f, [inputs.contiguous(), scales.contiguous(), means.contiguous()])
-        with torch.no_grad():  # the quantised values themselves are plumbing (WACNN.forward discards them, cnn.py:171)
-            outputs = inputs + noise if training else torch.round(inputs - means) + means
+        # entropy_models.py:126-150,655: outputs = quantize(inputs, "noise" | "dequantize", means) WITH its gradient:
+        # d/d inputs = 1 (noise) or 0 (round), d/d means = 0 (noise) or 1 (dequantize adds the means back after the round)
+        outputs = _QuantizeOut.apply(self, inputs, means, noise)
         return outputs, lik

@@ -101,18 +101,24 @@ class GradReducer:
 
     def __init__(self, flat_g: torch.Tensor, ranges, group=None):
         self.g, self.ranges, self.group = flat_g, list(ranges), group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        # ICM_FORCE_COLLECTIVES=1 (tests): run the collective path even in a 1-rank group, so that the side-stream
+        # async all-reduce / event ordering / Work.wait() sequence executes on a single-GPU box under RCCL
+        self.active = self.world > 1 or (inited and os.environ.get("ICM_FORCE_COLLECTIVES", "0") == "1")
         self.cuda = flat_g.is_cuda
-        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         self.works = []
+        self.launched = 0     # collectives issued (tests)
 
     def launch(self, bucket: int):
-        if self.world == 1:
+        if not self.active:
             return
         a, b = self.ranges[bucket]
         if b <= a:
             return
         t = self.g[a:b]
+        self.launched += 1
         if self.cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal path (several ranks sharing one GPU): stage through the host
             torch.cuda.current_stream().synchronize()
@@ -146,9 +152,9 @@ class Trainer:
         self.lr, self.aux_lr, self.lmbda, self.clip = lr, aux_lr, lmbda, clip_max_norm
         self.reducer = GradReducer(self.flat.g, self.flat.bucket_ranges, group)
         self.world = self.reducer.world
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.rank = dist.get_rank(group) if self.reducer.active else 0
         # replicas start from rank 0's parameters (what DistributedDataParallel does at construction) ...
-        if self.world > 1:
+        if self.reducer.active:
             for buf in (self.flat.p, self.flat.ap):
                 _broadcast0(buf, group)
         # ... but draw their OWN quantisation noise / DropPath masks: one generator per rank, seeded seed + rank

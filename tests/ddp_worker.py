@@ -25,6 +25,7 @@ def inputs():
 
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"   # "nccl" = RCCL: one rank per GPU (1-rank group on a 1-GPU box)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     import torch
@@ -32,7 +33,9 @@ def main():
     from oracle import weights as W
     from icm_amd.trainer import Trainer
     from icm_amd.zoo import models
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         net = models["cnn"]()
         net.load_state_dict(W.make_wacnn_state_dict(salt=0 if rank == 0 else 7))
@@ -45,11 +48,14 @@ def main():
         x, noises = inputs()
         scal = []
         for it in range(2):
-            nz = {k: v[rank:rank + 1] for k, v in noises[it].items()}
-            scal.append(tr.step(x[rank:rank + 1].cuda(), nz).cpu())
+            lo, hi = (rank, rank + 1) if world > 1 else (0, 2)   # a 1-rank group trains on the whole batch
+            nz = {k: v[lo:hi] for k, v in noises[it].items()}
+            scal.append(tr.step(x[lo:hi].cuda(), nz).cpu())
         torch.cuda.synchronize()
         torch.save({"p": tr.flat.p.cpu(), "ap": tr.flat.ap.cpu(), "g": tr.flat.g.cpu(), "scal": scal, "p_init": p_init,
-                    "fired": fired}, os.path.join(outdir, f"rank{rank}.pt"))
+                    "fired": fired, "backend": dist.get_backend(), "world": dist.get_world_size(),
+                    "collectives": tr.reducer.launched, "side_stream": tr.reducer.stream is not None},
+                   os.path.join(outdir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
 

@@ -51,6 +51,30 @@ def test_image_folder(tmp_path):
         D.ImageFolder(str(tmp_path), split="nope")
 
 
+def test_image_folder_vs_reference_fixture(golden_dir):
+    """icm_amd.datasets.ImageFolder against what the reference's own class (datasets/utils.py:23-89) returned for the
+    committed folder tests/golden/imagefolder (fixture written by tests/golden/make_golden_imagefolder.py from the real
+    class): same sample set, bit-identical RGB arrays for RGB / grey / RGBA / palette / BMP files, the value handed to
+    a transform, the error for a missing split.  (The reference lists samples in directory order; the mirror sorts.)"""
+    z = np.load(os.path.join(golden_dir, "imagefolder.npz"), allow_pickle=False)
+    root = os.path.join(golden_dir, "imagefolder")
+    ds = D.ImageFolder(root, split="train")
+    assert len(ds) == int(z["len"])
+    assert [p.name for p in ds.samples] == [str(n) for n in z["names"]]
+    got = []
+    ds_t = D.ImageFolder(root, transform=lambda im: (got.append(im.mode), np.asarray(im))[1], split="train")
+    for i, p_ in enumerate(ds.samples):
+        im = ds[i]
+        assert im.mode == "RGB"
+        ref = z["img." + p_.name]
+        assert np.array_equal(np.asarray(im), ref), p_.name
+        assert np.array_equal(ds_t[i], ref)
+    assert got == ["RGB"] * len(ds)
+    with pytest.raises(RuntimeError) as ei:
+        D.ImageFolder(root, split="missing")
+    assert str(ei.value).replace(root, "<root>") == str(z["missing_split_raises"])
+
+
 def test_center_crop_semantics():
     a = _img(21, 30, 7)
     im = Image.fromarray(a)

@@ -202,3 +202,36 @@ def test_uninitialised_tables_raise():
         m.compress(torch.rand(1, 3, 64, 64, device=DEV))
     with pytest.raises(ValueError):
         m.compress(torch.rand(1, 3, 65, 64, device=DEV))
+
+
+def test_decompress_with_a_second_instance_built_from_the_state_dict(net):
+    """Cross-instance determinism: the streams of one model instance are decoded by ANOTHER instance that was built
+    from the saved state_dict only (weights + the _quantized_cdf / _offset / _cdf_length buffers; no update() call),
+    the way a decoder process would be set up from a checkpoint (models/base.py:62-70, eval_model/__main__.py:141-151).
+    The reconstruction must be bit-identical to the encoder instance's own decompress().  Also: update(force=True)
+    twice on the first instance (buffers re-allocated, possibly at recycled addresses) must leave its host table cache
+    consistent with the buffers (streams unchanged)."""
+    import io
+    from icm_amd.zoo import models
+    x = W._u("cc.x2nd", (1, 3, 128, 64), 0.0, 1.0).to(DEV)
+    enc = net.compress(x)
+    ref = net.decompress(enc["strings"], enc["shape"])["x_hat"]
+    buf = io.BytesIO()
+    torch.save({k: v.cpu() for k, v in net.state_dict().items()}, buf)
+    buf.seek(0)
+    sd = torch.load(buf, weights_only=True)
+    other = models["cnn"]()
+    other.load_state_dict(sd)
+    other = other.to(DEV).eval()
+    for name in ("_quantized_cdf", "_offset", "_cdf_length"):
+        for mod in ("entropy_bottleneck", "gaussian_conditional"):
+            assert torch.equal(getattr(getattr(other, mod), name).cpu(), getattr(getattr(net, mod), name).cpu()), (mod, name)
+    dec = other.decompress(enc["strings"], enc["shape"])["x_hat"]
+    assert torch.equal(dec, ref)
+    assert [bytes(s) for part in other.compress(x)["strings"] for s in part] == \
+           [bytes(s) for part in enc["strings"] for s in part]
+    # table-cache invalidation: rebuild the tables twice, then code again
+    net.update(force=True)
+    net.update(force=True)
+    again = net.compress(x)
+    assert [bytes(s) for part in again["strings"] for s in part] == [bytes(s) for part in enc["strings"] for s in part]

@@ -69,3 +69,35 @@ def test_two_ranks_equal_one_rank_on_the_full_batch():
     print(f"2 ranks vs 1 rank: relative L2 error of the 2-step update {l2:.2e}, max abs parameter diff {err.abs().max().item():.2e}")
     assert l2 < 3e-4 and err.abs().max().item() < 2e-5     # measured 3.2e-5 / 5.2e-6
     assert (r0["ap"] - tr.flat.ap.cpu()).abs().max().item() < 1e-6
+
+
+def test_rccl_one_rank_collective_path_is_bit_identical():
+    """The RCCL branch of GradReducer (side-stream async all_reduce, event ordering against the weight-gradient side
+    stream, Work.wait() in finish(), device-tensor broadcast) on a one-GPU box: a fresh child process initialises a
+    1-rank `nccl` process group with ICM_FORCE_COLLECTIVES=1, so every bucket goes through dist.all_reduce on the
+    reducer's stream.  A sum over one rank is the identity: parameters, gradients and loss scalars after two steps must
+    equal the group-less run BIT FOR BIT."""
+    sys.path.insert(0, HERE)
+    import ddp_worker
+    from oracle import weights as W
+    from icm_amd.trainer import Trainer
+    from icm_amd.zoo import models
+    port = str(_free_port())
+    with tempfile.TemporaryDirectory() as out:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ICM_FORCE_COLLECTIVES="1")
+        p = subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_worker.py"), "0", "1", port, out, "nccl"], env=env)
+        assert p.wait(timeout=900) == 0
+        r0 = torch.load(os.path.join(out, "rank0.pt"), weights_only=True)
+    assert r0["backend"] == "nccl" and r0["world"] == 1
+    assert r0["side_stream"] and r0["collectives"] == 8 and r0["fired"] == [0, 1, 2, 3] * 2
+    net = models["cnn"]()
+    net.load_state_dict(W.make_wacnn_state_dict())
+    tr = Trainer(net, lr=1e-4, aux_lr=1e-4, lmbda=0.0067, clip_max_norm=1.0, device="cuda:0")
+    assert not tr.reducer.active
+    x, noises = ddp_worker.inputs()
+    scal = [tr.step(x.cuda(), noises[it]).cpu() for it in range(2)]
+    torch.cuda.synchronize()
+    assert torch.equal(r0["p"], tr.flat.p.cpu()) and torch.equal(r0["ap"], tr.flat.ap.cpu())
+    assert torch.equal(r0["g"], tr.flat.g.cpu())
+    for it in range(2):
+        assert torch.equal(r0["scal"][it], scal[it])
