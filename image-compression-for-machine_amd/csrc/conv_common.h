@@ -73,10 +73,6 @@ __device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& 
       v[q] = acc[half * 8 + q] + bv[q];
       if constexpr (EPI == ICM_EPI_RES) v[q] += rv[q];
       if constexpr (EPI == ICM_EPI_RES_GELU) v[q] += gelu_f(rv[q]);
-      if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
-        // materialised activation for the consumers of this pre-activation (forward only): y2 = gelu(y)
-        if (y2b && ok[q]) y2b[off[q]] = gelu_f(v[q]);
-      }
       if constexpr (EPI == ICM_EPI_GDN || EPI == ICM_EPI_IGDN) {
         if (y2b && ok[q]) y2b[off[q]] = v[q];
         v[q] = av[q] * (EPI == ICM_EPI_GDN ? rsqrtf(v[q]) : sqrtf(v[q]));
@@ -90,12 +86,21 @@ __device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& 
         v[q] = av[q] + 0.5f * t;
       }
     }
-    if (d.accum) {   // gradient accumulation: one more batched read of the destination
+    if (d.accum) {   // accumulation (gradients; partial first-layer sums of the slice chains): one more batched read
       float old[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) old[q] = ok[q] ? yb[off[q]] : 0.0f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] += old[q];
+    }
+    if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
+      // materialised activation for the consumers of this pre-activation (forward only): y2 = gelu(y), of the value
+      // AFTER an accumulation (the launch that completes a partial sum materialises it)
+      if (y2b) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (ok[q]) y2b[off[q]] = gelu_f(v[q]);
+      }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
@@ -180,6 +185,13 @@ __device__ __forceinline__ void epi_finish(const ConvDesc& d, const ConvPtrs& P,
   if (d.accum) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] += R.old[q];
+  }
+  if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
+    if (y2b) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (R.ok[q]) y2b[R.off[q]] = gelu_f(v[q]);
+    }
   }
 #pragma unroll
   for (int q = 0; q < 8; ++q)

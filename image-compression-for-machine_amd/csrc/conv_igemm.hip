@@ -275,6 +275,8 @@ struct PackDesc {
   float* wp;
   int Co, Ci, KHW, src_out_major, ntaps, ncot, nchunks, nonneg;
   float bound, pedestal;
+  int src_ld, src_off;          // sub-matrix of a wider weight: row length / first entry of the inner matrix index
+  int dst_ncot, dst_cot_off;    // concatenation along GEMM-M: tiles per step of the destination, first tile of this job
   short tapidx[ICM_MAX_TAPS];
 };
 
@@ -305,10 +307,10 @@ __device__ __forceinline__ void pack_unit(const PackDesc& d, int cot, int chunk,
         lo[u] = r * rstride + c;
         if (d.src_out_major) {
           const int co = co0 + r, ci = ci0 + c / KHW;
-          if (co < d.Co && ci < d.Ci) v[u] = d.w[((long long)co * d.Ci + ci0) * KHW + c];
+          if (co < d.Co && ci < d.Ci) v[u] = d.w[((long long)co * d.src_ld + d.src_off + ci0) * KHW + c];
         } else {
           const int ci = ci0 + r, co = co0 + c / KHW;
-          if (ci < d.Ci && co < d.Co) v[u] = d.w[((long long)ci * d.Co + co0) * KHW + c];
+          if (ci < d.Ci && co < d.Co) v[u] = d.w[((long long)ci * d.src_ld + d.src_off + co0) * KHW + c];
         }
       }
     }
@@ -337,7 +339,7 @@ __device__ __forceinline__ void pack_unit(const PackDesc& d, int cot, int chunk,
       const bool valid = (co0 + col < d.Co) && (ci0 + cil < d.Ci);
       o[j] = valid ? v : 0.0f;   // padded rows / channels are exact zeros (also under the nonneg transform)
     }
-    out[((long long)(chunk * d.ntaps + t) * d.ncot + cot) * 64 + lane] = o;
+    out[((long long)(chunk * d.ntaps + t) * d.dst_ncot + d.dst_cot_off + cot) * 64 + lane] = o;
   }
   __syncthreads();
 }
@@ -489,7 +491,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   const int ncot = cdiv(a.Cout, 32), nchunks8 = cdiv(a.Cin, 8);
   const int ntaps = (int)cls.taps.size();
   if (ntaps > ICM_MAX_TAPS) return ICM_ERR_UNSUPPORTED;
-  if (ntaps == 1 && S_in == 1 && out_s == 1 && cls.iy0 == 0 && cls.ix0 == 0) {
+  if (ntaps == 1 && S_in == 1 && out_s == 1 && cls.iy0 == 0 && cls.ix0 == 0 && a.x_seg_len == 0) {
     const int rc = (g_force_cfg >= 0) ? -1 : run_conv1x1(arr, ngroups, wp_off, g_force_1x1, stream);
     if (rc >= 0) return rc;
   }
@@ -557,7 +559,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     const bool epi_ok = a.epi == ICM_EPI_NONE || a.epi == ICM_EPI_RES || a.epi == ICM_EPI_RES_GELU ||
                         a.epi == ICM_EPI_MUL_DGELU || a.epi == ICM_EPI_LRP || a.epi == ICM_EPI_RES_MUL_DGELU;
     if ((ks8_on && g_force_cfg < 0 || g_force_cfg == 100 || g_force_cfg == 101) && S_in == 1 && ntaps > 1 &&
-        a.pro_act == ICM_ACT_NONE && epi_ok) {
+        a.pro_act == ICM_ACT_NONE && epi_ok && a.x_seg_len == 0) {
       const int tco = g_force_cfg == 101 ? 1 : (g_force_cfg == 100 ? 2 : (ncot >= 2 ? 2 : 1));
       const int bpx = tco == 2 ? 64 : 128;
       Geometry g = make_geometry(bpx, OHv, OWv, a.N, S_in, cls.ey, cls.ex, nchunks8, ntaps, 4);
@@ -596,6 +598,8 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
   pg.dTIPH = make_fastdiv((uint32_t)pg.TIPH);
   pg.dPH = make_fastdiv((uint32_t)bg.PH);
   pg.H = a.H; pg.W = a.W; pg.N = a.N; pg.C = a.Cin; pg.act = a.pro_act; pg.bs = a.x_bs;
+  pg.seg_len = a.x_seg_len; pg.seg_gap = a.x_seg_len ? a.x_seg_gap : 0;
+  pg.dseg = make_fastdiv((uint32_t)std::max(1, a.x_seg_len));
   {
     const int TW = 1 << bg.lgTW;
     const int plane4 = (1 << bg.lgTI) * bg.PH * (bg.PW / 4);
@@ -603,6 +607,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
               (a.W % 4) == 0 && (a.x_bs % 4) == 0 && ((long long)a.H * a.W % 4) == 0 && plane4 <= 4 * 64 &&
               (bg.CS % 4) == 0 && (bg.PWrow % 4) == 0 && (bg.PP % 4) == 0;
     for (int gi = 0; gi < ngroups; ++gi) v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[gi].x) & 15) == 0);
+    if (a.x_seg_len) v4 = false;   // (the packed vec4 form moves several channels per instruction: keep segments simple)
     pg.vec4 = v4 ? 1 : 0;
     // LDS-DMA staging: no activation to apply, linear patch layout (stride-1 input sampling: no column-parity split),
     // not the 16-byte halo-free path (4x the bytes per instruction)
@@ -660,6 +665,7 @@ static int validate(const icm_conv_args& a) {
   if (((long long)a.N * a.x_bs + 8LL * a.H * a.W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32
   if (a.pixel_shuffle != 0 && a.pixel_shuffle != 2) return ICM_ERR_UNSUPPORTED;
   if (a.pixel_shuffle == 2 && (a.Cout % 4 != 0 || a.transposed)) return ICM_ERR_ARG;
+  if (a.x_seg_len < 0 || (a.x_seg_len > 0 && (a.x_seg_gap < 0 || a.x_seg_len >= 65536))) return ICM_ERR_ARG;
   return ICM_OK;
 }
 
@@ -670,6 +676,20 @@ static int conv_run_grouped(const icm_conv_args* arr, int ngroups, hipStream_t s
     if (rc) return rc;
   }
   const icm_conv_args& a = arr[0];
+  // one launch, one geometry: every member must agree with arr[0] in everything but its pointers (the kernel takes
+  // shapes, strides, epilogue kind and flags from arr[0]; a mismatching member would read / write out of bounds)
+  for (int i = 1; i < ngroups; ++i) {
+    const icm_conv_args& b = arr[i];
+    if (b.N != a.N || b.Cin != a.Cin || b.H != a.H || b.W != a.W || b.Cout != a.Cout || b.OH != a.OH || b.OW != a.OW ||
+        b.KH != a.KH || b.KW != a.KW || b.stride != a.stride || b.pad != a.pad || b.transposed != a.transposed ||
+        b.pro_act != a.pro_act || b.epi != a.epi || b.accum != a.accum || b.pixel_shuffle != a.pixel_shuffle ||
+        b.x_bs != a.x_bs || b.y_bs != a.y_bs || b.x_seg_len != a.x_seg_len || b.x_seg_gap != a.x_seg_gap ||
+        (b.res && b.res_bs != a.res_bs) || (b.aux && b.aux_bs != a.aux_bs) || (b.aux2 && b.aux2_bs != a.aux2_bs) ||
+        (b.y2 && b.y2_bs != a.y2_bs) || (b.res != nullptr) != (a.res != nullptr) || (b.aux != nullptr) != (a.aux != nullptr) ||
+        (b.aux2 != nullptr) != (a.aux2 != nullptr) || (b.y2 != nullptr) != (a.y2 != nullptr) ||
+        (b.bias != nullptr) != (a.bias != nullptr))
+      return ICM_ERR_ARG;
+  }
   std::vector<ConvClass> classes = build_classes(a.KH, a.KW, a.stride, a.pad, a.transposed);
   const int ncot = cdiv(a.Cout, 32), nchunks = cdiv(a.Cin, 8);
   long long off = 0;
@@ -731,6 +751,7 @@ int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int K
     d.Co = Cout; d.Ci = Cin; d.KHW = KH * KW; d.src_out_major = src_out_major;
     d.ntaps = ntaps; d.ncot = ncot; d.nchunks = nchunks; d.nonneg = nonneg;
     d.bound = bound; d.pedestal = pedestal;
+    d.src_ld = src_out_major ? Cin : Cout; d.src_off = 0; d.dst_ncot = ncot; d.dst_cot_off = 0;
     for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
     for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
     const long long total = (long long)nchunks * ntaps * ncot * 256;
@@ -762,6 +783,10 @@ int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
       return ICM_ERR_ARG;
     std::vector<ConvClass> classes = build_classes(J.KH, J.KW, J.stride, J.pad, J.transposed);
     const int ncot = cdiv(J.Cout, 32), nchunks = cdiv(J.Cin, 8);
+    const int inner = J.src_out_major ? J.Cin : J.Cout;
+    const int src_ld = J.src_ld > 0 ? J.src_ld : inner;
+    const int dst_ncot = J.dst_ncot > 0 ? J.dst_ncot : ncot;
+    if (J.src_off < 0 || J.src_off + inner > src_ld || J.dst_cot_off < 0 || J.dst_cot_off + ncot > dst_ncot) return ICM_ERR_ARG;
     long long off = 0;
     for (const ConvClass& cls : classes) {
       const int ntaps = (int)cls.taps.size();
@@ -772,9 +797,10 @@ int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
       d.Co = J.Cout; d.Ci = J.Cin; d.KHW = J.KH * J.KW; d.src_out_major = J.src_out_major;
       d.ntaps = ntaps; d.ncot = ncot; d.nchunks = nchunks; d.nonneg = J.nonneg;
       d.bound = J.bound; d.pedestal = J.pedestal;
+      d.src_ld = src_ld; d.src_off = J.src_off; d.dst_ncot = dst_ncot; d.dst_cot_off = J.dst_cot_off;
       for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
       for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
-      off += (long long)nchunks * ntaps * ncot * 256;
+      off += (long long)nchunks * ntaps * dst_ncot * 256;   // class stride of the (possibly concatenated) destination
       if (++nb == ICM_PACK_NB) {
         int rc = flush();
         if (rc) return rc;

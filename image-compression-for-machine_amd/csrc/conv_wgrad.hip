@@ -779,6 +779,7 @@ struct RedPtrs {
   const float* dbias_ws;
   float* dbias;
   int accum, accum_bias;
+  int dw_ld;   // row length (in b-columns) of the destination tensor: Cb, or the full input-channel count of a wider weight
 };
 struct RedDesc {
   RedPtrs g[WG_MAXG];
@@ -836,7 +837,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
       f32x4 t = part[pl];
 #pragma unroll
       for (int u = 1; u < 16; ++u) t += part[u * 16 + pl];
-      f32x4* o = reinterpret_cast<f32x4*>(G.dw + ab);
+      const long long ar = ab / d.Cb;   // (Cb % 4 == 0 and dw_ld % 4 == 0 when dw_ld != Cb: host-checked)
+      f32x4* o = reinterpret_cast<f32x4*>(G.dw + (G.dw_ld == d.Cb ? ab : ar * G.dw_ld + (ab - ar * d.Cb)));
       if (G.accum) t += *o;
       *o = t;
     }
@@ -871,12 +873,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   }
   __syncthreads();
   const int nv = (int)min((long long)64, CaCb - ab0);
-  float* o = G.dw + ab0 * ntaps;
-  for (int e = threadIdx.x; e < nv * ntaps; e += 256) {
-    const int abl = e / ntaps, t = e - abl * ntaps;
-    float v = tile[t][abl];
-    if (G.accum) v += o[e];
-    o[e] = v;
+  if (G.dw_ld == d.Cb) {
+    float* o = G.dw + ab0 * ntaps;
+    for (int e = threadIdx.x; e < nv * ntaps; e += 256) {
+      const int abl = e / ntaps, t = e - abl * ntaps;
+      float v = tile[t][abl];
+      if (G.accum) v += o[e];
+      o[e] = v;
+    }
+  } else {   // column block of a wider weight: rows are dw_ld * ntaps floats apart
+    for (int e = threadIdx.x; e < nv * ntaps; e += 256) {
+      const int abl = e / ntaps, t = e - abl * ntaps;
+      const long long abg = ab0 + abl, ar = abg / d.Cb;
+      float* o = G.dw + (ar * G.dw_ld + (abg - ar * d.Cb)) * ntaps + t;
+      float v = tile[t][abl];
+      if (G.accum) v += *o;
+      *o = v;
+    }
   }
 }
 
@@ -1110,6 +1123,8 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
     d.g[i].dbias_ws = b.dbias ? b.ws + slab_all : nullptr;
     r.g[i].ws = b.ws; r.g[i].dw = b.dw; r.g[i].dbias_ws = d.g[i].dbias_ws; r.g[i].dbias = b.dbias;
     r.g[i].accum = b.accum; r.g[i].accum_bias = b.accum_bias;
+    r.g[i].dw_ld = b.dw_ld > 0 ? b.dw_ld : a->Cb;
+    if (r.g[i].dw_ld < a->Cb) return ICM_ERR_ARG;
   }
   d.gs_bs = a->gs_bs;
   PatchGeom& pg = d.pg;
@@ -1182,8 +1197,10 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   {
     const long long CaCb = (long long)a->Ca * a->Cb;
     bool v4 = ntaps == 1 && (CaCb % 4) == 0;
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
       v4 = v4 && ((reinterpret_cast<uintptr_t>(arr[i].ws) & 15) == 0) && ((reinterpret_cast<uintptr_t>(arr[i].dw) & 15) == 0);
+      if (r.g[i].dw_ld != a->Cb) v4 = v4 && (a->Cb % 4) == 0 && (r.g[i].dw_ld % 4) == 0;
+    }
     r.vec4 = v4 ? 1 : 0;
     r.nwblocks = (int)((CaCb + 63) / 64);   // 16 float4 positions (1x1) or 64 positions (multi-tap) per workgroup
   }

@@ -87,7 +87,13 @@ struct PatchGeom {
   int pipe;   // weight-gradient loaders: two register sets, next batch in flight while this one is stored
   int dma;    // stage by LDS-DMA (no activation, linear patch layout; host-checked): stage_planes_dma
   int v4R, v4P2;   // vec4 with a small plane: one load instruction covers v4R channels, v4P2 lanes each (set_v4_pack)
+  int seg_len, seg_gap;   // blocked channel map (0 = none): logical channel c -> plane c + (c / seg_len) * seg_gap
+  FastDiv dseg;
 };
+// physical channel plane of logical channel c (wave-uniform in every caller)
+__device__ __forceinline__ int phys_ch(const PatchGeom& g, int c) {
+  return g.seg_len ? c + (int)fdiv((uint32_t)c, g.dseg) * g.seg_gap : c;
+}
 // vec4 staging of small planes (1x1 convolutions on 64..128-pixel tiles fill only 16..32 of the 64 lanes with one
 // channel): pack R = 64 / P2 channels into every load instruction, P2 = lanes per channel (power of two >= plane4)
 inline void set_v4_pack(PatchGeom& g) {
@@ -179,7 +185,7 @@ __device__ __forceinline__ void stage_planes_t_v4(const float* __restrict__ src,
     for (int u = 0; u < CPB * NJR; ++u) {
       const int k = kb + u / NJR, j = u % NJR;
       const int cl = (lw + 4 * k) * R;            // first local channel of the group (wave-uniform)
-      const char* base = srcb + (long long)(c0 + cl) * HWb;
+      const char* base = srcb + (long long)phys_ch(g, c0 + cl) * HWb;   // (a v4R group never straddles a segment: host-checked)
       if (k < nk && cl + m.lc < nch && c0 + cl + m.lc < g.C && m.goff[j] >= 0)
         v[u] = *reinterpret_cast<const f32x4*>(base + m.goff[j]);
       else v[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -250,7 +256,7 @@ __device__ __forceinline__ void stage_planes_t(const float* __restrict__ src, co
     for (int u = 0; u < CPB * NJR; ++u) {
       const int k = kb + u / NJR, j = u % NJR;
       const int c = c0 + lw + 4 * k;
-      const char* base = srcb + (long long)c * HWb;
+      const char* base = srcb + (long long)phys_ch(g, c) * HWb;
       v[u] = (k < nk && c < g.C && m.goff[j] >= 0) ? *reinterpret_cast<const float*>(base + m.goff[j]) : 0.0f;
     }
   };
@@ -311,7 +317,7 @@ __device__ __forceinline__ void stage_planes_dma_t(const float* __restrict__ src
   const float* zero = icm_zero_page + lane;
   for (int k = 0; k < nk; ++k) {
     const int cl = lw + 4 * k, c = c0 + cl;
-    const char* base = srcb + (long long)c * HWb;
+    const char* base = srcb + (long long)phys_ch(g, c) * HWb;
     float* slab = dst + cl * g.CS;
 #pragma unroll
     for (int j = 0; j < NJR; ++j) {

@@ -156,6 +156,16 @@ __global__ void ste_round_offset_kernel(const float* z, const float* quant, floa
     zh[i] = ((rintf(t) - t) + t) + med;
   }
 }
+#define ICM_GATHER_MAX 64
+struct GatherPtrs {
+  const float* p[ICM_GATHER_MAX];
+};
+// dst[i * len + e] = srcs[i][e]: the first-layer biases of all slice chains as one vector (cnn.py:89-127)
+__global__ __launch_bounds__(256) void gather_vectors_kernel(const GatherPtrs P, int len, float* __restrict__ dst) {
+  const float* src = P.p[blockIdx.x];
+  for (int e = threadIdx.x; e < len; e += 256) dst[(long long)blockIdx.x * len + e] = src[e];
+}
+
 __global__ void copy_strided_kernel(const float* src, long long sbs, float* dst, long long dbs, int N, int C, int HW,
                                     int accum) {
   const long long per = (long long)C * HW, n = (long long)N * per;
@@ -721,6 +731,16 @@ int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_b
   if (!src || !dst || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ST, src,
                      (long long)src_bs, dst, (long long)dst_bs, N, C, HW, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_gather_vectors(const float* const* srcs, int n, int len, float* dst, void* stream) {
+  if (!srcs || !dst || n < 1 || n > ICM_GATHER_MAX || len <= 0) return ICM_ERR_ARG;
+  icm::GatherPtrs P;
+  for (int i = 0; i < ICM_GATHER_MAX; ++i) P.p[i] = srcs[i < n ? i : 0];
+  for (int i = 0; i < n; ++i)
+    if (!srcs[i]) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(icm::gather_vectors_kernel, dim3(n), dim3(256), 0, ST, P, len, dst);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

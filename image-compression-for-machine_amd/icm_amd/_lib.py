@@ -28,7 +28,7 @@ class ConvArgs(C.Structure):
         ("transposed", i32), ("pro_act", i32), ("epi", i32),
         ("res", vp), ("res_bs", i64), ("aux", vp), ("aux_bs", i64), ("aux2", vp), ("aux2_bs", i64),
         ("y2", vp), ("y2_bs", i64),
-        ("accum", i32), ("pixel_shuffle", i32),
+        ("accum", i32), ("pixel_shuffle", i32), ("x_seg_len", i32), ("x_seg_gap", i32),
     ]
 
 
@@ -38,13 +38,14 @@ class WgradArgs(C.Structure):
         ("gb", vp), ("gb_bs", i64), ("Cb", i32), ("H", i32), ("W", i32), ("act_b", i32),
         ("N", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
         ("dw", vp), ("ws", vp), ("accum", i32),
-        ("dbias", vp), ("accum_bias", i32), ("ws_floats", i64),
+        ("dbias", vp), ("accum_bias", i32), ("ws_floats", i64), ("dw_ld", i32),
     ]
 
 
 class PackJob(C.Structure):
     _fields_ = [("w", vp), ("wp", vp), ("Cout", i32), ("Cin", i32), ("KH", i32), ("KW", i32), ("src_out_major", i32),
-                ("transposed", i32), ("stride", i32), ("pad", i32), ("nonneg", i32), ("bound", f32), ("pedestal", f32)]
+                ("transposed", i32), ("stride", i32), ("pad", i32), ("nonneg", i32), ("bound", f32), ("pedestal", f32),
+                ("src_ld", i32), ("src_off", i32), ("dst_ncot", i32), ("dst_cot_off", i32)]
 
 
 class EbParams(C.Structure):
@@ -68,7 +69,7 @@ SYMBOLS = [
     "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_layernorm_fwd", "icm_layernorm_bwd", "icm_space_to_depth2",
-    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_winattn_fwd", "icm_winattn_bwd",
+    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_gather_vectors", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_adam_step_hyper", "icm_fill",
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_force_conv1x1",
@@ -107,6 +108,7 @@ def lib():
         L.icm_conv_wgrad.argtypes = [C.POINTER(WgradArgs), vp]
         L.icm_conv_wgrad_grouped.argtypes = [C.POINTER(WgradArgs), i32, vp]
         L.icm_channel_sum.argtypes = [vp, i64, i32, i32, i32, vp, i32, vp, i64, vp]
+        L.icm_gather_vectors.argtypes = [C.POINTER(vp), i32, i32, vp, vp]
         L.icm_nonneg_fwd.argtypes = [vp, vp, i64, f32, f32, vp]
         L.icm_nonneg_bwd.argtypes = [vp, vp, vp, i64, f32, i32, vp]
         L.icm_gdn_bwd_pre.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp]

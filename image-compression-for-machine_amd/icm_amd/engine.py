@@ -231,57 +231,95 @@ class Tape:
         return self._ws
 
     def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0):
-        """MFMA-fragment-order copy of a weight for this step.  With ``pack_seq`` (the miss sequence recorded on an
-        earlier, identical step) a miss packs a short WINDOW of upcoming weights in one launch: the ~830 tiny
-        per-layer pack launches of a training step become ~40, while every packed weight is still produced just
-        before its consumer (packing everything up front pushes it out of the Infinity Cache: DESIGN.md 5)."""
-        args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg)
-        k = (w.data_ptr(), w._version, _weight_gen[0]) + args
+        """MFMA-fragment-order copy of a weight for this step (one packing job; see pack_entry)."""
+        args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg, float(bound), float(ped), 0, 0, 0, 0)
+        floats = L.lib().icm_packed_weight_floats(M, K, KH, KW)
+        return self.pack_entry(((w.data_ptr(),), (args,)), floats, [(w, args, 0)])
+
+    def pack_cat(self, members, M, K, KH, KW, src_out_major, transposed, stride, pad, axis: str):
+        """ONE packed buffer holding sub-matrices of several weights laid end to end along a GEMM axis, so that a single
+        launch contracts what the reference runs as separate first layers of the slice chains (cnn.py:89-127).
+        members: [(w, col_off)]: member m contributes columns [col_off, col_off + count) of the INNER matrix index of
+        its canonical weight (input channels of a Conv2d weight), count = K for the forward orientation
+        (src_out_major=1), M for the input-gradient orientation (src_out_major=0).
+        axis "M": the members' M rows are concatenated (each M rows, a multiple of 32): forward, outputs side by side.
+        axis "K": the members' K channels are concatenated (each K, a multiple of 8): one contraction over all of them.
+        M, K are PER MEMBER."""
+        n = len(members)
+        lib = L.lib()
+        per = lib.icm_packed_weight_floats(M, K, KH, KW)
+        if axis == "M":
+            if M % 32:
+                raise ValueError("pack_cat: M-concatenation needs members of a multiple of 32 rows")
+            ncot = M // 32
+        elif K % 8:
+            raise ValueError("pack_cat: K-concatenation needs members of a multiple of 8 channels")
+        jobs, ids, argl = [], [], []
+        for m, (w, col) in enumerate(members):
+            ld = w.shape[1]   # canonical Conv2d weight [Cout][Cin_total][KH][KW]: the inner index is the input channel
+            if axis == "M":
+                a = (M, K, KH, KW, src_out_major, transposed, stride, pad, 0, 0.0, 0.0, ld, col, n * ncot, m * ncot)
+                off = 0
+            else:
+                a = (M, K, KH, KW, src_out_major, transposed, stride, pad, 0, 0.0, 0.0, ld, col, 0, 0)
+                off = m * per
+            jobs.append((w, a, off))
+            ids.append(w.data_ptr())
+            argl.append(a)
+        return self.pack_entry((tuple(ids), tuple(argl), axis), n * per, jobs)
+
+    def pack_entry(self, ident, floats, jobs):
+        """ident: hashable, stable across steps (weight addresses + job arguments); jobs: [(w, args15, float offset)].
+        With ``pack_seq`` (the miss sequence recorded on an earlier, identical step) a miss packs a short WINDOW of
+        upcoming entries in one launch: the ~830 tiny per-layer pack launches of a training step become ~40, while every
+        packed weight is still produced just before its consumer (packing everything up front pushes it out of the
+        Infinity Cache: DESIGN.md 5)."""
+        vers = tuple(w._version for w, _, _ in jobs)
+        k = (ident, vers, _weight_gen[0])
         wp = self._packed.get(k)
         if wp is not None:
             return wp
         if self.pack_log is not None:
-            self.pack_log.append((w, args + (bound, ped)))
-        lib = L.lib()
+            self.pack_log.append((ident, floats, jobs))
+        todo = [(k, floats, jobs)]
         seq = self.pack_seq
         if seq is not None:
-            i = self._seq_pos.get((w.data_ptr(),) + args) if self._seq_pos is not None else None
+            i = self._seq_pos.get(ident) if self._seq_pos is not None else None
             if i is not None:
-                jobs_w = []
-                for (w2, a2) in seq[i:i + self.pack_window]:
-                    k2 = (w2.data_ptr(), w2._version, _weight_gen[0]) + a2[:9]
+                todo = []
+                for (id2, fl2, jobs2) in seq[i:i + self.pack_window]:
+                    k2 = (id2, tuple(w._version for w, _, _ in jobs2), _weight_gen[0])
                     if k2 not in self._packed:
-                        wp2 = torch.empty(lib.icm_packed_weight_floats(a2[0], a2[1], a2[2], a2[3]), dtype=torch.float32,
-                                          device=w2.device)
-                        self._packed[k2] = wp2
-                        jobs_w.append((w2, a2, wp2))
-                jobs = (L.PackJob * len(jobs_w))()
-                for j, (w2, a2, wp2) in zip(jobs, jobs_w):
-                    j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w2), ptr(wp2), a2[0], a2[1], a2[2], a2[3]
-                    j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal = a2[4:11]
-                e0 = _prof_begin()
-                check(lib.icm_pack_weights_batch(jobs, len(jobs_w), self.st), "pack_weights_batch")
-                _prof_end(e0, "pack weights (window)", 0.0)
-                return self._packed[k]
-        wp = torch.empty(lib.icm_packed_weight_floats(M, K, KH, KW), dtype=torch.float32, device=w.device)
+                        todo.append((k2, fl2, jobs2))
+        dev = jobs[0][0].device
+        flat = []
+        for k2, fl2, jobs2 in todo:
+            buf = torch.empty(fl2, dtype=torch.float32, device=dev)
+            self._packed[k2] = buf
+            for w2, a2, off in jobs2:
+                flat.append((w2, a2, ptr(buf) + 4 * off))
+        arr = (L.PackJob * len(flat))()
+        for j, (w2, a2, wpp) in zip(arr, flat):
+            j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w2), wpp, a2[0], a2[1], a2[2], a2[3]
+            (j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal, j.src_ld, j.src_off,
+             j.dst_ncot, j.dst_cot_off) = a2[4:15]
         e0 = _prof_begin()
-        check(lib.icm_pack_weights(ptr(w), ptr(wp), M, K, KH, KW, src_out_major, transposed, stride, pad,
-                                   nonneg, bound, ped, self.st), "pack_weights")
-        _prof_end(e0, "pack weights (single)", 0.0)
-        self._packed[k] = wp
-        return wp
+        check(L.lib().icm_pack_weights_batch(arr, len(flat), self.st), "pack_weights_batch")
+        _prof_end(e0, "pack weights (window)" if len(todo) > 1 else "pack weights (single)", 0.0)
+        return self._packed[k]
 
     def use_pack_sequence(self, seq, window: int = 24):
-        """seq: list of (w, (M, K, KH, KW, som, tr, stride, pad, nonneg, bound, ped)) in miss order (a ``pack_log``)"""
+        """seq: list of (ident, floats, jobs) in miss order (a ``pack_log``)"""
         self.pack_seq, self.pack_window = seq, window
         self._seq_pos = {}
-        for i, (w, a) in enumerate(seq):
-            self._seq_pos.setdefault((w.data_ptr(),) + a[:9], i)
+        for i, (ident, _, _) in enumerate(seq):
+            self._seq_pos.setdefault(ident, i)
 
 
 # ------------------------------------------------------------------------------------------------ raw launches
 def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW, pro_act=ACT_NONE,
-                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0, tag="fwd"):
+                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0, tag="fwd", seg=None):
+    """seg = (run length, gap): blocked input-channel map (icm_conv_args.x_seg_len / x_seg_gap)"""
     a = L.ConvArgs()
     N, _, H, W = x.shape
     e0 = _prof_begin()
@@ -295,6 +333,8 @@ def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transpo
     a.aux2, a.aux2_bs = ptr(aux2), bs(aux2)
     a.y2, a.y2_bs = ptr(y2), bs(y2)
     a.accum, a.pixel_shuffle = accum, ps
+    if seg is not None:
+        a.x_seg_len, a.x_seg_gap = seg
     check(L.lib().icm_conv_run(C.byref(a), tape.st), "conv_run")
     if e0 is not None:
         px = H * W if transposed else OH * OW
@@ -323,13 +363,14 @@ def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NON
 
 
 def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
-                dbias=None, accum_bias=0):
+                dbias=None, accum_bias=0, dw_ld=0):
     """Queue a weight-gradient problem.  Nothing but the optimiser consumes a weight gradient, so problems are
-    collected while the tape unwinds and issued in batches of identical geometry (flush_wgrads)."""
+    collected while the tape unwinds and issued in batches of identical geometry (flush_wgrads).
+    dw_ld > 0: dw points at a column block of a [Ca][dw_ld][KH][KW] tensor (icm_wgrad_args.dw_ld)."""
     N, _, OH, OW = gs.shape
     _, _, H, W = gb.shape
     key = (Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, bs(gs), bs(gb), dbias is not None)
-    tape.wjobs.append((key, gs, gb, dw, accum, dbias, accum_bias))
+    tape.wjobs.append((key, gs, gb, dw, accum, dbias, accum_bias, dw_ld))
 
 
 def flush_wgrads(tape):
@@ -360,12 +401,13 @@ def flush_wgrads(tape):
         for i0 in range(0, len(jobs), 32):
             chunk = jobs[i0:i0 + 32]
             arr = (L.WgradArgs * len(chunk))()
-            for a, (_, gs, gb, dw, accum, dbias, accum_bias) in zip(arr, chunk):
+            for a, (_, gs, gb, dw, accum, dbias, accum_bias, dw_ld) in zip(arr, chunk):
                 a.gs, a.gs_bs, a.Ca, a.OH, a.OW, a.act_s = ptr(gs), gsb, Ca, OH, OW, act_s
                 a.gb, a.gb_bs, a.Cb, a.H, a.W, a.act_b = ptr(gb), gbb, Cb, H, W, act_b
                 a.N, a.KH, a.KW, a.stride, a.pad = N, KH, KW, stride, pad
                 a.dw, a.accum = ptr(dw), accum
                 a.dbias, a.accum_bias = ptr(dbias), accum_bias
+                a.dw_ld = dw_ld
             n = lib.icm_wgrad_workspace_floats_grouped(C.byref(arr[0]), len(chunk))
             if n < 0:
                 raise ValueError("icm wgrad: invalid geometry")

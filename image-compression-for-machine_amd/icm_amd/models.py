@@ -167,6 +167,14 @@ def _copy_op(tape, src, dst):
         tape.bw.append(bwd)
 
 
+# ICM_SLICE_SPLIT=1 (default): the first layer of every slice chain is split by input-channel block (slices.py): the
+# latent block of all 3 * num_slices chains runs as two wide convolutions outside the serial slice loop.  0 = the
+# literal per-chain form below (cat -> chain), kept for same-box A/B measurements and as a second implementation the
+# parity tests compare against.
+import os as _os
+SLICE_SPLIT = _os.environ.get("ICM_SLICE_SPLIT", "1") != "0"
+
+
 def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, num_slices: int,
                  max_support: int, keep: Optional[dict] = None, bucket_marks: Optional[dict] = None,
                  batch_tail: bool = True, codec: Optional[dict] = None, decode: Optional[dict] = None):
@@ -178,6 +186,11 @@ def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, nois
     decode (decompress(), cnn.py:289-326): {"z_hat", "M", "slice": callable(i, mu, sc, yh_pre)} -- y is None; the
     SAME launch sequence runs (identical kernels on identical inputs give the bit-identical mu / scale the encoder saw,
     which the CDF indexes depend on), but each slice's y_hat_pre comes from the entropy decoder instead of from y."""
+    if SLICE_SPLIT and batch_tail:
+        from .slices import hyper_slices_split
+        return hyper_slices_split(tape, P, y, noise_z, noise_y, num_slices, max_support, keep, bucket_marks, codec,
+                                  decode, lambda t, P_, y_: _chain(t, P_, "h_a", VT(y_), strides=(1, 1, 2, 1, 2)),
+                                  _h_s_pair, _record_symbols)
     if decode is not None:
         z_hat = decode["z_hat"].contiguous()
         dev, N, M = z_hat.device, z_hat.shape[0], decode["M"]

@@ -72,8 +72,12 @@ typedef struct icm_conv_args {
   const float* aux; int64_t aux_bs;
   const float* aux2; int64_t aux2_bs;
   float* y2; int64_t y2_bs;
-  int accum;          /* y += result instead of y = result (gradient accumulation) */
+  int accum;          /* y += result instead of y = result (gradient accumulation; with y2: y2 = gelu(y after the add)) */
   int pixel_shuffle;  /* 2: fuse nn.PixelShuffle(2) into the store (layers.py:34-38); y plane is (2*OH,2*OW), Cout/4 channels */
+  /* blocked input-channel map (0 = none): logical channel c reads plane c + (c / x_seg_len) * x_seg_gap of x -- the
+   * K-concatenation of equally long channel runs that lie x_seg_len + x_seg_gap planes apart (the first-layer input
+   * gradients of all slice chains of one family, cnn.py:89-127, contracted in ONE launch) */
+  int x_seg_len, x_seg_gap;
 } icm_conv_args;
 
 int icm_conv_run(const icm_conv_args* a, void* stream);
@@ -100,6 +104,14 @@ typedef struct icm_pack_job {
   const float* w; float* wp;
   int Cout, Cin, KH, KW, src_out_major, transposed, stride, pad, nonneg;
   float bound, pedestal;
+  /* sub-matrix of a wider canonical weight: the source rows hold src_ld (0 = natural) entries of the INNER matrix index
+   * (Cin when src_out_major, else Cout) and the job takes the entries [src_off, src_off + count) -- the input-channel
+   * blocks of the slice chains' first layers (cnn.py:89-127: latent | support slices | own slice) */
+  int src_ld, src_off;
+  /* concatenation along GEMM-M: the destination holds dst_ncot (0 = natural) 32-row tiles per (chunk, tap) step and
+   * this job's tiles start at dst_cot_off.  (Concatenation along GEMM-K needs no field: consecutive jobs write
+   * consecutive chunk ranges, i.e. wp advanced by icm_packed_weight_floats of the preceding jobs.) */
+  int dst_ncot, dst_cot_off;
 } icm_pack_job;
 int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream);
 
@@ -114,6 +126,8 @@ typedef struct icm_wgrad_args {
   float* dw; float* ws; int accum;
   float* dbias; int accum_bias;   /* optional: dbias[a] (+)= sum_{n,p} actS(gs[n,a,p]) (conv bias gradient, fused) */
   int64_t ws_floats;              /* capacity of ws in floats; 0 = unchecked. Too small -> ICM_ERR_ARG, nothing launched */
+  int dw_ld;                      /* 0 = Cb; else the gradient lands in a [Ca][dw_ld][KH][KW] tensor whose b-columns
+                                   * start at dw (an input-channel block of a wider weight); may differ per group member */
 } icm_wgrad_args;
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a);
 /* workspace PER PROBLEM when n problems of this geometry are issued by one icm_conv_wgrad_grouped call (the pixel
@@ -153,6 +167,9 @@ int icm_lrp_bwd(const float* g, int64_t g_bs, const float* t, int64_t t_bs, floa
                 int HW, void* stream);
 /* inverse of nn.PixelShuffle(2) (layers.py:34-38) for the subpel conv backward: src [N][C][2H][2W] -> dst [N][4C][H][W] */
 int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+/* dst[i*len + e] = srcs[i][e], i < n <= 64 (srcs: HOST array of device pointers): small parameter vectors laid end
+ * to end -- the first-layer biases of the slice chains whose first layers run as one concatenated GEMM */
+int icm_gather_vectors(const float* const* srcs, int n, int len, float* dst, void* stream);
 /* strided 4-D copy (chunk/cat plumbing): dst[n,c,p] (+)= src[n,c,p] */
 int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int N, int C, int HW, int accum, void* stream);
 

@@ -807,3 +807,141 @@ def test_conv_ks8_fused_neighbours():
         E._MAT_MIN_PIXELS = min_px
     finally:
         lib.icm_debug_force_conv_cfg(-1)
+
+
+def test_entropy_model_outputs_are_differentiable():
+    """GaussianConditional.forward / EntropyBottleneck.forward return (outputs, likelihood) with outputs =
+    quantize(inputs, "noise" | "dequantize", means) INCLUDING its gradient (entropy_models.py:126-150,468-472,655):
+    identity to the inputs in noise mode; zero to the inputs and one to the means in dequantize mode."""
+    import torch
+    from icm_amd.entropy_models import EntropyBottleneck, GaussianConditional
+    from oracle import weights as W
+    dev = "cuda:0"
+    y = W._u("qo.y", (2, 6, 4, 4), -4.0, 4.0).to(dev).requires_grad_(True)
+    mu = W._u("qo.mu", (2, 6, 4, 4), -1.0, 1.0).to(dev).requires_grad_(True)
+    sc = W._u("qo.sc", (2, 6, 4, 4), 0.2, 2.0).to(dev).requires_grad_(True)
+    w = W._u("qo.w", (2, 6, 4, 4), -1.0, 1.0).to(dev)
+    gc = GaussianConditional(None).to(dev)
+    # eval: outputs = round(y - mu) + mu
+    out, lik = gc(y, sc, mu, training=False)
+    assert torch.equal(out.detach(), torch.round(y.detach() - mu.detach()) + mu.detach())
+    (gy, gm) = torch.autograd.grad((out * w).sum(), [y, mu], allow_unused=True)
+    assert gy is None or float(gy.abs().max()) == 0.0
+    assert torch.equal(gm, w)
+    # train: outputs = y + noise
+    noise = W._u("qo.n", (2, 6, 4, 4), -0.5, 0.5)
+    gc.inject_noise(noise)
+    out, lik = gc(y, sc, mu, training=True)
+    assert torch.allclose(out.detach(), y.detach() + noise.to(dev), atol=1e-7)
+    gy, gm, gs = torch.autograd.grad((out * w).sum() + lik.sum(), [y, mu, sc])
+    out2, lik2 = gc(y, sc, mu, training=True)
+    gy2, gm2, gs2 = torch.autograd.grad(lik2.sum(), [y, mu, sc])
+    assert torch.allclose(gy - gy2, w, atol=1e-6) and torch.equal(gm, gm2) and torch.equal(gs, gs2)
+    # EntropyBottleneck: the same through the fused tape op
+    eb = EntropyBottleneck(6).to(dev)
+    z = W._u("qo.z", (2, 6, 3, 3), -3.0, 3.0).to(dev).requires_grad_(True)
+    wz = W._u("qo.wz", (2, 6, 3, 3), -1.0, 1.0).to(dev)
+    nz = W._u("qo.nz", (2, 6, 3, 3), -0.5, 0.5)
+    eb.inject_noise(nz)
+    zt, zl = eb(z, training=True)
+    (g1,) = torch.autograd.grad((zt * wz).sum() + zl.sum(), [z])
+    zt, zl = eb(z, training=True)
+    (g2,) = torch.autograd.grad(zl.sum(), [z])
+    assert torch.allclose(g1 - g2, wz, atol=1e-6)
+    zt, zl = eb(z, training=False)
+    med = eb.quantiles[:, 0, 1].reshape(1, -1, 1, 1).detach()
+    assert torch.equal(zt.detach(), torch.round(z.detach() - med) + med)
+    gz, gq = torch.autograd.grad((zt * wz).sum(), [z, eb.quantiles], allow_unused=True)
+    assert gz is None or float(gz.abs().max()) == 0.0
+    assert torch.allclose(gq[:, 0, 1], wz.sum(dim=(0, 2, 3)), atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ first-layer split pieces
+@pytest.mark.parametrize("N,h,w", [(2, 8, 8), (16, 16, 16)])
+def test_split_first_layer_pieces_vs_torch(N, h, w):
+    """The building blocks of icm_amd/slices.py against torch on the CPU: (a) packed weights that are column blocks of
+    wider canonical weights, concatenated along GEMM-M (forward of several chains' latent blocks in one launch);
+    (b) a second input-channel block accumulated in place with the materialised GELU written after the add; (c) the
+    input gradient of (a) as ONE contraction over the K-concatenated channels, also through the blocked channel map
+    (runs of channels lying apart in a wider buffer); (d) weight gradients written into column blocks of the wider
+    tensors (dw_ld)."""
+    from icm_amd import engine as E
+    from icm_amd import _lib as L
+    d = dev()
+    C1, C2, D0 = 40, 24, 64
+    w1, w2 = U("sp.w1", (D0, C1 + C2, 3, 3), -0.2, 0.2), U("sp.w2", (D0, C1 + 8, 3, 3), -0.2, 0.2)
+    b1 = U("sp.b1", (D0,))
+    x1, x2 = U("sp.x1", (N, C1, h, w)), U("sp.x2", (N, C2, h, w))
+    W1, W2, X1, X2, B1 = (t.to(d) for t in (w1, w2, x1, x2, b1))
+    tape = E.Tape(need_grad=False)
+    conv = dict(KH=3, KW=3, stride=1, pad=1, OH=h, OW=w)
+    # (a) latent blocks of both weights side by side: PRE[:, :64] = conv(x1, w1[:, :C1]), PRE[:, 64:] = conv(x1, w2[:, :C1])
+    PRE = torch.full((N, 3 * D0, h, w), 7.0, device=d)       # a third, untouched run in the middle (blocked map below)
+    wpA = tape.pack_cat([(W1, 0), (W2, 0)], D0, C1, 3, 3, 1, 0, 1, 1, "M")
+    tmp = torch.empty((N, 2 * D0, h, w), device=d)
+    E.conv_launch(tape, X1, wpA, None, tmp, Cin=C1, Cout=2 * D0, transposed=0, **conv)
+    close(tmp[:, :D0], F.conv2d(x1, w1[:, :C1], None, padding=1), what="A/w1")
+    close(tmp[:, D0:], F.conv2d(x1, w2[:, :C1], None, padding=1), what="A/w2")
+    PRE[:, :D0] = tmp[:, :D0]
+    PRE[:, 2 * D0:] = tmp[:, D0:]
+    # (b) the support block of w1 accumulated in place (+ bias here), GELU of the SUM materialised
+    G = torch.zeros((N, D0, h, w), device=d)
+    wpB = tape.pack_cat([(W1, C1)], D0, C2, 3, 3, 1, 0, 1, 1, "M")
+    E.conv_launch_grouped(tape, [X2], [wpB], [B1], [PRE[:, :D0]], Cin=C2, Cout=D0, transposed=0, y2s=[G], accum=1, **conv)
+    full = F.conv2d(torch.cat([x1, x2], 1), w1, b1, padding=1)
+    close(PRE[:, :D0], full, what="A+B")
+    close(G, F.gelu(full), what="gelu(A+B)")
+    assert float((PRE[:, D0:2 * D0] - 7.0).abs().max()) == 0.0
+    # (c) d x1 = sum over both chains: one contraction over K = 2*D0, contiguous and through the blocked map
+    g = U("sp.g", (N, 2 * D0, h, w))
+    ref_dx = (torch.nn.grad.conv2d_input(x1.shape, w1[:, :C1].contiguous(), g[:, :D0].contiguous(), padding=1) +
+              torch.nn.grad.conv2d_input(x1.shape, w2[:, :C1].contiguous(), g[:, D0:].contiguous(), padding=1))
+    wpK = tape.pack_cat([(W1, 0), (W2, 0)], C1, D0, 3, 3, 0, 1, 1, 1, "K")
+    Gd = g.to(d)
+    dx = torch.empty((N, C1, h, w), device=d)
+    E.conv_launch(tape, Gd, wpK, None, dx, Cin=2 * D0, Cout=C1, transposed=1, **conv)
+    close(dx, ref_dx, tol=5e-5, what="dgrad K-concat")
+    Gw = torch.full((N, 3 * D0, h, w), float("nan"), device=d)     # runs 0 and 2 of three: the middle one must not be read
+    Gw[:, :D0] = Gd[:, :D0]
+    Gw[:, 2 * D0:] = Gd[:, D0:]
+    dx2 = torch.zeros((N, C1, h, w), device=d)
+    E.conv_launch(tape, Gw, wpK, None, dx2, Cin=2 * D0, Cout=C1, transposed=1, seg=(D0, D0), **conv)
+    assert torch.equal(dx2, dx)
+    # (d) weight gradients into column blocks of the canonical tensors
+    gw1 = torch.zeros_like(W1)
+    gb1 = torch.zeros_like(B1)
+    t2 = E.Tape(need_grad=True)
+    E.wgrad_defer(t2, Gd[:, :D0], X1, gw1[:, :C1], Ca=D0, Cb=C1, KH=3, KW=3, stride=1, pad=1, accum=1, dbias=gb1,
+                  accum_bias=0, dw_ld=C1 + C2)
+    E.wgrad_defer(t2, Gd[:, :D0], X2, gw1[:, C1:], Ca=D0, Cb=C2, KH=3, KW=3, stride=1, pad=1, accum=1, dw_ld=C1 + C2)
+    E.flush_wgrads(t2)
+    ref_w = torch.nn.grad.conv2d_weight(torch.cat([x1, x2], 1), w1.shape, g[:, :D0].contiguous(), padding=1)
+    close(gw1, ref_w, tol=5e-5, what="wgrad blocks")
+    close(gb1, g[:, :D0].sum(dim=(0, 2, 3)), tol=5e-5, what="bias grad")
+    torch.cuda.synchronize()
+
+
+def test_grouped_conv_rejects_mismatching_members():
+    """C ABI: the members of a grouped launch must agree with member 0 in everything but their pointers"""
+    import ctypes as C
+    from icm_amd import _lib as L
+    d = dev()
+    x = torch.zeros((2, 8, 8, 8), device=d)
+    y = torch.zeros((2, 32, 8, 8), device=d)
+    wp = torch.zeros(L.lib().icm_packed_weight_floats(32, 8, 3, 3), device=d)
+
+    def arg(**over):
+        a = L.ConvArgs()
+        a.x, a.x_bs, a.N, a.Cin, a.H, a.W = x.data_ptr(), 8 * 64, 2, 8, 8, 8
+        a.wp, a.y, a.y_bs, a.Cout, a.OH, a.OW = wp.data_ptr(), y.data_ptr(), 32 * 64, 32, 8, 8
+        a.KH, a.KW, a.stride, a.pad = 3, 3, 1, 1
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+    ok = (L.ConvArgs * 2)(arg(), arg())
+    assert L.lib().icm_conv_run_grouped(ok, 2, L.stream()) == 0
+    for over in (dict(y_bs=16 * 64), dict(Cin=4), dict(Cout=16), dict(accum=1), dict(epi=L.EPI_MUL_DGELU),
+                 dict(x_seg_len=4, x_seg_gap=4), dict(pro_act=L.ACT_GELU)):
+        bad = (L.ConvArgs * 2)(arg(), arg(**over))
+        assert L.lib().icm_conv_run_grouped(bad, 2, L.stream()) == 1, over
+    torch.cuda.synchronize()
