@@ -262,6 +262,10 @@ __device__ __forceinline__ void epilogue_dispatch(const ConvDesc& d, const ConvP
 // tco = 1: 32 co x 128 px); d must describe a stride-1-sampling, activation-free, linear-patch launch
 int launch_conv_ks8(const ConvDesc& d, int tco, long long nblk, int ngroups, size_t lds_bytes, hipStream_t stream);
 
+// Winograd F(2x2, 3x3) path (conv_wino.hip): 3x3 stride-1 pad-1 launches whose weights were packed with wino != 0
+bool wino_supported(const icm_conv_args& a);
+int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream);
+
 // pointwise path (conv_1x1.hip): ICM_OK after launching, -1 when the launch should take the LDS-staged kernel
 int run_conv1x1(const icm_conv_args* arr, int ngroups, long long wp_off, int force_mode, hipStream_t stream);
 

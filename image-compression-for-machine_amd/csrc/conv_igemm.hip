@@ -277,6 +277,8 @@ struct PackDesc {
   float bound, pedestal;
   int src_ld, src_off;          // sub-matrix of a wider weight: row length / first entry of the inner matrix index
   int dst_ncot, dst_cot_off;    // concatenation along GEMM-M: tiles per step of the destination, first tile of this job
+  int wino;                     // 0: spatial taps; 1 / 2: Winograd F(2x2,3x3) weights U = G g G^T of the 3x3 kernel (2: of
+                                // the 180-degree rotated kernel = input-gradient orientation): 16 "taps" = transform points
   short tapidx[ICM_MAX_TAPS];
 };
 
@@ -335,7 +337,23 @@ __device__ __forceinline__ void pack_unit(const PackDesc& d, int cot, int chunk,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int cil = 2 * j + hh;
-      float v = d.src_out_major ? lds[col * rstride + cil * KHW + k] : lds[cil * rstride + col * KHW + k];
+      const float* gsrc = d.src_out_major ? lds + col * rstride + cil * KHW : lds + cil * rstride + col * KHW;
+      float v;
+      if (d.wino) {
+        // U[a][b] = sum_pq G[a][p] g[p][q] G[b][q],  G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]   (t = 4 a + b)
+        const int wa = t >> 2, wb = t & 3;
+        float row[3];   // (g G^T)[p][wb]
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const float g0 = gsrc[d.wino == 2 ? (2 - p) * 3 + 2 : p * 3 + 0];
+          const float g1 = gsrc[d.wino == 2 ? (2 - p) * 3 + 1 : p * 3 + 1];
+          const float g2 = gsrc[d.wino == 2 ? (2 - p) * 3 + 0 : p * 3 + 2];
+          row[p] = wb == 0 ? g0 : (wb == 3 ? g2 : (wb == 1 ? 0.5f * ((g0 + g2) + g1) : 0.5f * ((g0 + g2) - g1)));
+        }
+        v = wa == 0 ? row[0] : (wa == 3 ? row[2] : (wa == 1 ? 0.5f * ((row[0] + row[2]) + row[1]) : 0.5f * ((row[0] + row[2]) - row[1])));
+      } else {
+        v = gsrc[k];
+      }
       const bool valid = (co0 + col < d.Co) && (ci0 + cil < d.Ci);
       o[j] = valid ? v : 0.0f;   // padded rows / channels are exact zeros (also under the nonneg transform)
     }
@@ -578,7 +596,7 @@ static int run_class(const icm_conv_args* arr, int ngroups, const ConvClass& cls
     }
   }
 
-  ConvDesc d;
+  ConvDesc d{};
   for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
     const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
     d.g[gi].x = s.x;
@@ -683,13 +701,15 @@ static int conv_run_grouped(const icm_conv_args* arr, int ngroups, hipStream_t s
     if (b.N != a.N || b.Cin != a.Cin || b.H != a.H || b.W != a.W || b.Cout != a.Cout || b.OH != a.OH || b.OW != a.OW ||
         b.KH != a.KH || b.KW != a.KW || b.stride != a.stride || b.pad != a.pad || b.transposed != a.transposed ||
         b.pro_act != a.pro_act || b.epi != a.epi || b.accum != a.accum || b.pixel_shuffle != a.pixel_shuffle ||
-        b.x_bs != a.x_bs || b.y_bs != a.y_bs || b.x_seg_len != a.x_seg_len || b.x_seg_gap != a.x_seg_gap ||
+        b.x_bs != a.x_bs || b.y_bs != a.y_bs || b.x_seg_len != a.x_seg_len || b.x_seg_gap != a.x_seg_gap || b.algo != a.algo ||
         (b.res && b.res_bs != a.res_bs) || (b.aux && b.aux_bs != a.aux_bs) || (b.aux2 && b.aux2_bs != a.aux2_bs) ||
         (b.y2 && b.y2_bs != a.y2_bs) || (b.res != nullptr) != (a.res != nullptr) || (b.aux != nullptr) != (a.aux != nullptr) ||
         (b.aux2 != nullptr) != (a.aux2 != nullptr) || (b.y2 != nullptr) != (a.y2 != nullptr) ||
         (b.bias != nullptr) != (a.bias != nullptr))
       return ICM_ERR_ARG;
   }
+  if (a.algo == ICM_ALGO_WINOGRAD) return run_conv_wino(arr, ngroups, stream);
+  if (a.algo != ICM_ALGO_DIRECT) return ICM_ERR_ARG;
   std::vector<ConvClass> classes = build_classes(a.KH, a.KW, a.stride, a.pad, a.transposed);
   const int ncot = cdiv(a.Cout, 32), nchunks = cdiv(a.Cin, 8);
   long long off = 0;
@@ -728,7 +748,10 @@ int icm_convT2d_fwd(const icm_conv_args* a, void* stream) {
   return icm_conv_run(a, stream);
 }
 
+int icm_conv_winograd_ok(const icm_conv_args* a) { return (a && icm::wino_supported(*a)) ? 1 : 0; }
+
 void icm_debug_force_conv_cfg(int idx) { icm::g_force_cfg = idx; }
+int icm_debug_forced_conv_cfg(void) { return icm::g_force_cfg; }
 void icm_debug_force_conv1x1(int mode) { icm::g_force_1x1 = mode; }
 
 int64_t icm_packed_weight_floats(int Cout, int Cin, int KH, int KW) {
@@ -745,13 +768,13 @@ int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int K
   for (const ConvClass& cls : classes) {
     const int ntaps = (int)cls.taps.size();
     if (ntaps == 0) continue;
-    PackDesc d;
+    PackDesc d{};
     d.w = w;
     d.wp = wp + off;
     d.Co = Cout; d.Ci = Cin; d.KHW = KH * KW; d.src_out_major = src_out_major;
     d.ntaps = ntaps; d.ncot = ncot; d.nchunks = nchunks; d.nonneg = nonneg;
     d.bound = bound; d.pedestal = pedestal;
-    d.src_ld = src_out_major ? Cin : Cout; d.src_off = 0; d.dst_ncot = ncot; d.dst_cot_off = 0;
+    d.src_ld = src_out_major ? Cin : Cout; d.src_off = 0; d.dst_ncot = ncot; d.dst_cot_off = 0; d.wino = 0;
     for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
     for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
     const long long total = (long long)nchunks * ntaps * ncot * 256;
@@ -767,7 +790,7 @@ int icm_pack_weights(const float* w, float* wp, int Cout, int Cin, int KH, int K
 int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
   using namespace icm;
   if (!jobs || n < 1) return ICM_ERR_ARG;
-  PackMulti m;
+  PackMulti m{};
   int nb = 0;
   auto flush = [&]() -> int {
     if (nb == 0) return ICM_OK;
@@ -782,6 +805,14 @@ int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
     if (!J.w || !J.wp || J.Cout <= 0 || J.Cin <= 0 || J.KH * J.KW > ICM_MAX_TAPS || (J.stride != 1 && J.stride != 2))
       return ICM_ERR_ARG;
     std::vector<ConvClass> classes = build_classes(J.KH, J.KW, J.stride, J.pad, J.transposed);
+    if (J.wino) {   // Winograd-domain weights of a 3x3 stride-1 kernel: one "class" of 16 transform points
+      if (J.wino < 0 || J.wino > 2 || J.KH != 3 || J.KW != 3 || J.stride != 1 || J.pad != 1 || J.nonneg) return ICM_ERR_ARG;
+      ConvClass wc;
+      wc.cy = wc.cx = wc.iy0 = wc.ix0 = 0;
+      wc.ey = wc.ex = 1;
+      for (int t = 0; t < 16; ++t) wc.taps.push_back({0, 0, 0});
+      classes.assign(1, wc);
+    }
     const int ncot = cdiv(J.Cout, 32), nchunks = cdiv(J.Cin, 8);
     const int inner = J.src_out_major ? J.Cin : J.Cout;
     const int src_ld = J.src_ld > 0 ? J.src_ld : inner;
@@ -797,7 +828,7 @@ int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream) {
       d.Co = J.Cout; d.Ci = J.Cin; d.KHW = J.KH * J.KW; d.src_out_major = J.src_out_major;
       d.ntaps = ntaps; d.ncot = ncot; d.nchunks = nchunks; d.nonneg = J.nonneg;
       d.bound = J.bound; d.pedestal = J.pedestal;
-      d.src_ld = src_ld; d.src_off = J.src_off; d.dst_ncot = dst_ncot; d.dst_cot_off = J.dst_cot_off;
+      d.src_ld = src_ld; d.src_off = J.src_off; d.dst_ncot = dst_ncot; d.dst_cot_off = J.dst_cot_off; d.wino = J.wino;
       for (int t = 0; t < ICM_MAX_TAPS; ++t) d.tapidx[t] = 0;
       for (int t = 0; t < ntaps; ++t) d.tapidx[t] = (short)cls.taps[t].kidx;
       off += (long long)nchunks * ntaps * dst_ncot * 256;   // class stride of the (possibly concatenated) destination

@@ -1115,8 +1115,8 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   const long long slab_all = (long long)nslab * ntaps * a->Ca * a->Cb;
   for (int i = 0; i < n; ++i)   // the slabs (+ bias partials) of this launch's split count must fit the caller's workspace
     if (arr[i].ws_floats > 0 && arr[i].ws_floats < slab_all + (long long)p.nsplit * a->Ca) return ICM_ERR_ARG;
-  WgDesc d;
-  RedDesc r;
+  WgDesc d{};
+  RedDesc r{};
   for (int i = 0; i < WG_MAXG; ++i) {
     const icm_wgrad_args& b = arr[i < n ? i : 0];
     d.g[i].gs = b.gs; d.g[i].gb = b.gb; d.g[i].ws = b.ws;
@@ -1134,6 +1134,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   pg.dTIPH = make_fastdiv((uint32_t)pg.TIPH);
   pg.dPH = make_fastdiv((uint32_t)p.PH);
   pg.H = a->H; pg.W = a->W; pg.N = a->N; pg.C = a->Cb; pg.act = a->act_b; pg.bs = a->gb_bs;
+  pg.seg_len = 0; pg.seg_gap = 0; pg.dseg = make_fastdiv(1);   // no blocked channel map on the weight-gradient operands
   {
     const int TW = 1 << p.lgTW;
     bool v4 = ntaps == 1 && a->stride == 1 && a->pad == 0 && p.lgNPX >= 5 && (TW % 4) == 0 && (a->W % 4) == 0 &&

@@ -1,0 +1,336 @@
+// 3x3 stride-1 pad-1 convolutions (forward and input gradient) as Winograd F(2x2, 3x3) on f32 MFMA for gfx950.
+//
+// Half of the model's contraction FLOP are 3x3 stride-1 convolutions (the 150 slice-chain layers, the ResidualUnit
+// 3x3s of the four attention gates, the hyper synthesis; cnn.py:54-127, layers.py:52-72).  For a 2x2 output tile
+//      Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input patch, g: 3x3 kernel,
+// the 36 multiply-adds per (ci, co) of the direct form become 16: the contraction over input channels runs in the
+// transform domain as 16 independent GEMMs  M[xi][co][tile] = sum_ci U[xi][co][ci] V[xi][ci][tile]  -- 4/9 of the
+// matrix-pipe work.  Everything stays f32; the transform matrices hold 0, +-1, +-1/2 only (measured error against the
+// direct kernel: a few 1e-7 of the tensor maximum, the same order as a change of summation order).
+//
+// Kernel structure (MI355X-first; same 4 MFMA + 4 loader wave split as conv_igemm.hip, one workgroup per CU):
+//   * workgroup = (TCO x 32 output channels) x (32 tiles = 128 output pixels), all 16 transform points;
+//   * loader waves: lane = (input channel of the 8-channel chunk, tile); it gathers its 4x4 patch straight from global
+//     memory (zero padding by mask, optional virtual activation), applies B^T d B in registers (32 add/sub) and writes
+//     the 16 transformed values to LDS as V[xi][ci][tile] -- exactly the B-fragment order of v_mfma_f32_32x32x2_f32
+//     (lane = (tile, k parity)), so MFMA waves read it with conflict-free, linear ds_read_b32.  Two chunks per
+//     barrier, double buffered, loads issued one full step (~4 000 cycles) before their transform;
+//   * MFMA wave r owns transform row r (xi = 4r .. 4r+3): 4 x TCO accumulator tiles; A fragments are the Winograd-domain
+//     weights U = G g G^T, pre-packed per step in fragment order (icm_pack_weights with wino != 0) and streamed from L2
+//     three units ahead;
+//   * epilogue: the column half of A^T M A happens in registers (each wave holds a whole row), the row half through
+//     LDS; every wave then finishes a quarter of the (channel, tile) elements: 2x2 pixels per lane with the fused
+//     neighbours of conv_common.h (bias, residual, GELU materialisation, GELU', LRP tanh, accumulation).
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include "conv_common.h"
+
+namespace icm {
+
+struct WinoDesc {
+  ConvPtrs g[ICM_MAX_GROUPS];
+  long long x_bs, y_bs, res_bs, aux_bs, y2_bs;
+  int N, Cin, Cout, H, W;
+  int lgTX, lgTY, lgTI, tiles_x, tiles_y, tiles_n;   // a block = (1 << lgTX) x (1 << lgTY) tiles of (1 << lgTI) images = 32 tiles
+  int ncot, nchunks8, ncb, nsteps;                    // nsteps = ceil(nchunks8 / 2): two 8-channel chunks per barrier
+  int epi, accum, act;
+  int seg_len, seg_gap;
+  FastDiv dseg;
+  int px_fast, npx;   // workgroup order: pixel blocks fastest (weights stationary per XCD) when the weights outweigh the activations
+};
+
+#define WINO_STEP_FLOATS (2 * 16 * 8 * 32)   /* V of one step: [chunk 2][xi 16][ci 8][tile 32] */
+
+template <int EPI>
+__device__ __forceinline__ void wino_finish(const WinoDesc& d, const ConvPtrs& P, float v, int co, long long off, bool ok) {
+  // one output element: bias / fused neighbour / accumulate / materialise / store (conv_common.h semantics)
+  if (!ok) return;
+  if (P.bias) v += P.bias[co];
+  if constexpr (EPI == ICM_EPI_RES) v += P.res[off];
+  if constexpr (EPI == ICM_EPI_RES_GELU) v += gelu_f(P.res[off]);
+  if constexpr (EPI == ICM_EPI_MUL_DGELU) v *= dgelu_f(P.aux[off]);
+  if constexpr (EPI == ICM_EPI_RES_MUL_DGELU) v = (v + P.res[off]) * dgelu_f(P.aux[off]);
+  if constexpr (EPI == ICM_EPI_LRP) {
+    const float t = tanhf(v);
+    if (P.y2) P.y2[off] = t;
+    v = P.aux[off] + 0.5f * t;
+  }
+  if (d.accum) v += P.y[off];
+  if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
+    if (P.y2) P.y2[off] = gelu_f(v);
+  }
+  P.y[off] = v;
+}
+
+template <int TCO>
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ConvPtrs P = d.g[blockIdx.y];
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  // Which operand should stay in the XCD's L2?  Consecutive logical blocks run together on one XCD.  Small weights
+  // (chain layers: 2.5 MB): co-blocks fastest -- the co-blocks of a pixel block share its activations.  Wide first-layer
+  // launches (87 MB of Winograd weights against 5 MB of activations): pixel blocks fastest, so each XCD streams only
+  // its own 1/8 of the weights instead of all of them once per pixel block.
+  const int cb = d.px_fast ? bid / d.npx : bid % d.ncb;
+  int pt = d.px_fast ? bid % d.npx : bid / d.ncb;
+  const int bx = pt % d.tiles_x;
+  pt /= d.tiles_x;
+  const int by = pt % d.tiles_y;
+  const int bn = pt / d.tiles_y;
+  const int TXm = (1 << d.lgTX) - 1, TYm = (1 << d.lgTY) - 1;
+  const int HW = d.H * d.W;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loader / input-transform waves
+    const int q = (wave - 4) * 64 + lane;
+    const int ci_l = q >> 5, t = q & 31;
+    const int tx = t & TXm, ty = (t >> d.lgTX) & TYm, ti = t >> (d.lgTX + d.lgTY);
+    const int n = (bn << d.lgTI) + ti;
+    const int oy = (((by << d.lgTY) + ty) << 1), ox = (((bx << d.lgTX) + tx) << 1);
+    unsigned mask = 0;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int iy = oy - 1 + dy, ix = ox - 1 + dx;
+        if (n < d.N && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) mask |= 1u << (dy * 4 + dx);
+      }
+    const float* xbase = P.x + ((long long)n * d.x_bs + (long long)(oy - 1) * d.W + (ox - 1));
+    const int act = d.act;
+    auto load = [&](float (&r)[2][16], int step) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = (step * 2 + k) * 8 + ci_l;
+        const bool cok = c < d.Cin;
+        const int cp = d.seg_len ? c + (int)fdiv((uint32_t)c, d.dseg) * d.seg_gap : c;
+        const float* pc = xbase + (long long)cp * HW;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 4; ++dx)
+            r[k][dy * 4 + dx] = (cok && ((mask >> (dy * 4 + dx)) & 1u)) ? pc[dy * d.W + dx] : 0.0f;
+      }
+    };
+    auto transform_store = [&](const float (&r)[2][16], int buf) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float dd[16], u[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dd[e] = act ? apply_act(r[k][e], act) : r[k][e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // rows of B^T d
+          u[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
+          u[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
+          u[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
+          u[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
+        }
+        float* dst = smem + buf * WINO_STEP_FLOATS + k * (16 * 256) + ci_l * 32 + t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // columns: (B^T d) B
+          dst[(i * 4 + 0) * 256] = u[i * 4 + 0] - u[i * 4 + 2];
+          dst[(i * 4 + 1) * 256] = u[i * 4 + 1] + u[i * 4 + 2];
+          dst[(i * 4 + 2) * 256] = u[i * 4 + 2] - u[i * 4 + 1];
+          dst[(i * 4 + 3) * 256] = u[i * 4 + 1] - u[i * 4 + 3];
+        }
+      }
+    };
+    float ra[2][16], rb[2][16];
+    load(ra, 0);
+    if (d.nsteps > 1) load(rb, 1);
+    transform_store(ra, 0);
+    __syncthreads();   // step 0 published
+    for (int s = 0; s < d.nsteps; s += 2) {
+      if (s + 2 < d.nsteps) load(ra, s + 2);
+      if (s + 1 < d.nsteps) transform_store(rb, 1);
+      __syncthreads();
+      if (s + 1 >= d.nsteps) break;
+      if (s + 3 < d.nsteps) load(rb, s + 3);
+      if (s + 2 < d.nsteps) transform_store(ra, 0);
+      __syncthreads();
+    }
+  } else {
+  // ------------------------------------------------------------------ MFMA waves: wave r = transform row r
+  const int r = wave;
+  f32x16 acc[4][TCO];
+  const int cot0 = cb * TCO;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[c][a][e] = 0.0f;
+  const char* wbase = reinterpret_cast<const char*>(P.wp);
+  unsigned wl[TCO];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a) wl[a] = (unsigned)(min(cot0 + a, d.ncot - 1) * 64 + lane) * 16u;
+  const long long qstride = (long long)d.ncot * 64 * 16;   // bytes between consecutive (chunk, xi) entries
+  const int nunits = d.nsteps * 8;                         // (chunk, column) units of this wave, two chunks per step
+  const int lastq = d.nchunks8 * 16 - 1;
+  auto wptr = [&](int g) -> const char* {                  // packed weights of unit g = chunk * 4 + column
+    const int qq = min((g >> 2) * 16 + 4 * r + (g & 3), lastq);
+    return wbase + qq * qstride;
+  };
+  f32x4 aq[4][TCO];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) aq[u][a] = *reinterpret_cast<const f32x4*>(wptr(u) + wl[a]);
+  // B fragment of (chunk k of the step, column c): V[k][4r + c][ci = 2j + h][tile l31] -- linear in the lane id
+  const int boff = (4 * r) * 256 + lane;
+  __syncthreads();   // step 0 staged
+  for (int s = 0; s < d.nsteps; ++s) {
+    const float* vb = smem + (s & 1) * WINO_STEP_FLOATS + boff;
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[0][j] = vb[j * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int g = s * 8 + u;
+      if (u + 1 < 8) {   // next unit's B fragment (same step: same buffer)
+        const float* nb = vb + ((u + 1) >> 2) * (16 * 256) + ((u + 1) & 3) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[(u + 1) & 1][j] = nb[j * 64];
+      }
+      const char* sp = wptr(min(g + 3, nunits - 1));
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[u & 3][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u & 3][a][j], bv[u & 1][j], acc[u & 3][a], 0, 0, 0);
+        aq[(u + 3) & 3][a] = *reinterpret_cast<const f32x4*>(sp + wl[a]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- output transform Y = A^T M A.  Column half in registers: Z[.][0] = M0 + M1 + M2, Z[.][1] = M1 - M2 - M3
+  float* zb = smem;   // [row r 4][cp 2][TCO][16 regs][64 lanes]   (the staging buffers are free: last barrier passed)
+#pragma unroll
+  for (int a = 0; a < TCO; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float m0 = acc[0][a][e], m1 = acc[1][a][e], m2 = acc[2][a][e], m3 = acc[3][a][e];
+      zb[(((r * 2 + 0) * TCO + a) * 16 + e) * 64 + lane] = (m0 + m1) + m2;
+      zb[(((r * 2 + 1) * TCO + a) * 16 + e) * 64 + lane] = (m1 - m2) - m3;
+    }
+  }
+  __syncthreads();   // Z complete (loader waves join here: the finishing work is spread over all eight waves)
+  // row half + epilogue: wave w finishes accumulator rows e = w and w + 8 of every co tile: 2x2 pixels per lane
+  const float* zb = smem;
+  const int cot0 = cb * TCO;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int tx = l31 & TXm, ty = (l31 >> d.lgTX) & TYm, ti = l31 >> (d.lgTX + d.lgTY);
+  const int n = (bn << d.lgTI) + ti;
+  const int oy = (((by << d.lgTY) + ty) << 1), ox = (((bx << d.lgTX) + tx) << 1);
+  const bool nok = n < d.N;
+  P.y += (long long)n * d.y_bs;
+  if (P.y2) P.y2 += (long long)n * d.y2_bs;
+  if (P.res) P.res += (long long)n * d.res_bs;
+  if (P.aux) P.aux += (long long)n * d.aux_bs;
+  auto finish_all = [&](auto epi_tag) {
+    constexpr int EPI = decltype(epi_tag)::value;
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+      const int cot = cot0 + a;
+      if (cot >= d.ncot) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = wave + 8 * i;
+        const int co = cot * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float z[4][2];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) z[rr][cp] = zb[(((rr * 2 + cp) * TCO + a) * 16 + e) * 64 + lane];
+        const bool cok = nok && co < d.Cout;
+        const long long base = (long long)co * HW + (long long)oy * d.W + ox;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+          const float y0 = (z[0][cp] + z[1][cp]) + z[2][cp];
+          const float y1 = (z[1][cp] - z[2][cp]) - z[3][cp];
+          const bool xok = cok && ox + cp < d.W;
+          wino_finish<EPI>(d, P, y0, co, base + cp, xok && oy < d.H);
+          wino_finish<EPI>(d, P, y1, co, base + d.W + cp, xok && oy + 1 < d.H);
+        }
+      }
+    }
+  };
+  switch (d.epi) {
+    case ICM_EPI_RES: finish_all(std::integral_constant<int, ICM_EPI_RES>{}); break;
+    case ICM_EPI_RES_GELU: finish_all(std::integral_constant<int, ICM_EPI_RES_GELU>{}); break;
+    case ICM_EPI_MUL_DGELU: finish_all(std::integral_constant<int, ICM_EPI_MUL_DGELU>{}); break;
+    case ICM_EPI_RES_MUL_DGELU: finish_all(std::integral_constant<int, ICM_EPI_RES_MUL_DGELU>{}); break;
+    case ICM_EPI_LRP: finish_all(std::integral_constant<int, ICM_EPI_LRP>{}); break;
+    default: finish_all(std::integral_constant<int, ICM_EPI_NONE>{}); break;
+  }
+}
+
+bool wino_supported(const icm_conv_args& a) {
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.pixel_shuffle) return false;
+  if (a.OH != a.H || a.OW != a.W) return false;
+  switch (a.epi) {
+    case ICM_EPI_NONE: case ICM_EPI_RES: case ICM_EPI_RES_GELU: case ICM_EPI_MUL_DGELU: case ICM_EPI_RES_MUL_DGELU:
+    case ICM_EPI_LRP: break;
+    default: return false;
+  }
+  if (a.pro_act != ICM_ACT_NONE && a.pro_act != ICM_ACT_GELU && a.pro_act != ICM_ACT_SQUARE) return false;
+  return true;
+}
+
+int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
+  const icm_conv_args& a = arr[0];
+  if (!wino_supported(a)) return ICM_ERR_UNSUPPORTED;
+  WinoDesc d{};
+  for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
+    const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
+    d.g[gi].x = s.x; d.g[gi].wp = s.wp; d.g[gi].bias = s.bias; d.g[gi].y = s.y;
+    d.g[gi].res = s.res; d.g[gi].aux = s.aux; d.g[gi].aux2 = nullptr; d.g[gi].y2 = s.y2;
+  }
+  d.x_bs = a.x_bs; d.y_bs = a.y_bs; d.res_bs = a.res_bs; d.aux_bs = a.aux_bs; d.y2_bs = a.y2_bs;
+  d.N = a.N; d.Cin = a.Cin; d.Cout = a.Cout; d.H = a.H; d.W = a.W;
+  const int tw = cdiv(a.W, 2), th = cdiv(a.H, 2);   // tiles per image row / column
+  d.lgTX = std::min(3, ceil_log2(tw));
+  d.lgTY = std::min(5 - d.lgTX, ceil_log2(th));
+  d.lgTI = 5 - d.lgTX - d.lgTY;
+  d.tiles_x = cdiv(tw, 1 << d.lgTX); d.tiles_y = cdiv(th, 1 << d.lgTY); d.tiles_n = cdiv(a.N, 1 << d.lgTI);
+  d.ncot = cdiv(a.Cout, 32); d.nchunks8 = cdiv(a.Cin, 8); d.nsteps = cdiv(d.nchunks8, 2);
+  d.epi = a.epi; d.accum = a.accum; d.act = a.pro_act;
+  d.seg_len = a.x_seg_len; d.seg_gap = a.x_seg_len ? a.x_seg_gap : 0;
+  d.dseg = make_fastdiv((uint32_t)std::max(1, a.x_seg_len));
+  const long long pblocks = (long long)d.tiles_x * d.tiles_y * d.tiles_n;
+  // co tiles per workgroup: 2 halves the activation staging per output; 1 gives twice the workgroups (small launches)
+  static const int force_tco = getenv("ICM_WINO_TCO") ? atoi(getenv("ICM_WINO_TCO")) : 0;
+  int tco = 2;
+  {
+    const long long b2 = pblocks * cdiv(d.ncot, 2) * ngroups, b1 = pblocks * d.ncot * ngroups;
+    const double t2 = std::ceil(b2 / 256.0) * 2.0, t1 = std::ceil(b1 / 256.0) * 1.0 * 1.08;
+    if (d.ncot == 1 || t1 < t2) tco = 1;
+    if (force_tco == 1 || force_tco == 2) tco = force_tco;
+    (void)b1;
+  }
+  d.ncb = cdiv(d.ncot, tco);
+  d.npx = (int)pblocks;
+  {
+    const double wbytes = 64.0 * a.Cin * a.Cout, abytes = 4.0 * a.Cin * a.N * a.H * a.W;
+    static const int force_order = getenv("ICM_WINO_PXFAST") ? atoi(getenv("ICM_WINO_PXFAST")) : -1;
+    d.px_fast = (wbytes > 3.0e6 && wbytes > abytes) ? 1 : 0;
+    if (force_order == 0 || force_order == 1) d.px_fast = force_order;
+  }
+  const long long nblk = pblocks * d.ncb;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
+  void (*fn)(const WinoDesc) = tco == 2 ? conv_wino_kernel<2> : conv_wino_kernel<1>;
+  const size_t lds = (size_t)2 * WINO_STEP_FLOATS * sizeof(float);   // 64 KB: two staging steps; the output transform reuses it
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ngroups, 1), dim3(512), lds, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
+}  // namespace icm

@@ -28,6 +28,24 @@ _SKIP_WGRAD = _os.environ.get("ICM_DEBUG_SKIP_WGRAD", "0") == "1"
 PAIR_GATE_BRANCHES = _os.environ.get("ICM_PAIR_GATE_BRANCHES", "1") == "1"
 
 
+# Winograd F(2x2, 3x3) for the 3x3 stride-1 pad-1 convolutions (forward and input gradient; csrc/conv_wino.hip):
+# ICM_WINO=0 keeps the direct implicit-GEMM form everywhere (same-box A/B, and the reference point of the parity tests)
+USE_WINO = _os.environ.get("ICM_WINO", "1") != "0"
+_WINO_MIN_CIN = int(_os.environ.get("ICM_WINO_MIN_CIN", "16"))
+# Small launches are latency-bound (prologue gather + transform, LDS round trip of the output transform): below this
+# many multiply-adds of the DIRECT form per launch / 9 (N * H * W * Cin * Cout * members) the direct kernels win
+# (measured on MI355X, profiles/r03_wino_vs_direct.txt)
+_WINO_MIN_WORK = float(_os.environ.get("ICM_WINO_MIN_WORK", "2.0e8"))
+_WINO_EPIS = (EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_MUL_DGELU, EPI_RES_MUL_DGELU, EPI_LRP)
+
+
+def wino_ok(KH, KW, stride, pad, Cin, ps=0, conv_transposed=False, work: float = 1e30) -> bool:
+    """should this convolution launch (forward or input gradient) run on the Winograd kernel? (the epilogue kinds of both
+    directions of a 3x3 stride-1 layer are all supported: icm_conv_winograd_ok).  work = N * H * W * Cin * Cout * members."""
+    return (USE_WINO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not ps and not conv_transposed and
+            Cin >= _WINO_MIN_CIN and work >= _WINO_MIN_WORK and L.lib().icm_debug_forced_conv_cfg() < 0)
+
+
 # In-place HIP updates (icm_adam_step) do not bump torch's tensor version counters: the trainer bumps this generation
 # after every optimiser step and every packed-weight cache key carries it, so a caller-owned ``packed_cache`` that
 # outlives a training step misses (re-packs) instead of silently serving stale weights.
@@ -230,13 +248,14 @@ class Tape:
             self._ws = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
         return self._ws
 
-    def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0):
-        """MFMA-fragment-order copy of a weight for this step (one packing job; see pack_entry)."""
-        args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg, float(bound), float(ped), 0, 0, 0, 0)
-        floats = L.lib().icm_packed_weight_floats(M, K, KH, KW)
+    def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0, wino=0):
+        """MFMA-fragment-order copy of a weight for this step (one packing job; see pack_entry).
+        wino: 1 / 2 = Winograd-domain weights (forward / input-gradient orientation) of a 3x3 stride-1 kernel."""
+        args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg, float(bound), float(ped), 0, 0, 0, 0, wino)
+        floats = L.lib().icm_packed_weight_floats(M, K, 4, 4) if wino else L.lib().icm_packed_weight_floats(M, K, KH, KW)
         return self.pack_entry(((w.data_ptr(),), (args,)), floats, [(w, args, 0)])
 
-    def pack_cat(self, members, M, K, KH, KW, src_out_major, transposed, stride, pad, axis: str):
+    def pack_cat(self, members, M, K, KH, KW, src_out_major, transposed, stride, pad, axis: str, wino=0):
         """ONE packed buffer holding sub-matrices of several weights laid end to end along a GEMM axis, so that a single
         launch contracts what the reference runs as separate first layers of the slice chains (cnn.py:89-127).
         members: [(w, col_off)]: member m contributes columns [col_off, col_off + count) of the INNER matrix index of
@@ -247,7 +266,7 @@ class Tape:
         M, K are PER MEMBER."""
         n = len(members)
         lib = L.lib()
-        per = lib.icm_packed_weight_floats(M, K, KH, KW)
+        per = lib.icm_packed_weight_floats(M, K, 4, 4) if wino else lib.icm_packed_weight_floats(M, K, KH, KW)
         if axis == "M":
             if M % 32:
                 raise ValueError("pack_cat: M-concatenation needs members of a multiple of 32 rows")
@@ -258,10 +277,10 @@ class Tape:
         for m, (w, col) in enumerate(members):
             ld = w.shape[1]   # canonical Conv2d weight [Cout][Cin_total][KH][KW]: the inner index is the input channel
             if axis == "M":
-                a = (M, K, KH, KW, src_out_major, transposed, stride, pad, 0, 0.0, 0.0, ld, col, n * ncot, m * ncot)
+                a = (M, K, KH, KW, src_out_major, transposed, stride, pad, 0, 0.0, 0.0, ld, col, n * ncot, m * ncot, wino)
                 off = 0
             else:
-                a = (M, K, KH, KW, src_out_major, transposed, stride, pad, 0, 0.0, 0.0, ld, col, 0, 0)
+                a = (M, K, KH, KW, src_out_major, transposed, stride, pad, 0, 0.0, 0.0, ld, col, 0, 0, wino)
                 off = m * per
             jobs.append((w, a, off))
             ids.append(w.data_ptr())
@@ -269,7 +288,7 @@ class Tape:
         return self.pack_entry((tuple(ids), tuple(argl), axis), n * per, jobs)
 
     def pack_entry(self, ident, floats, jobs):
-        """ident: hashable, stable across steps (weight addresses + job arguments); jobs: [(w, args15, float offset)].
+        """ident: hashable, stable across steps (weight addresses + job arguments); jobs: [(w, args16, float offset)].
         With ``pack_seq`` (the miss sequence recorded on an earlier, identical step) a miss packs a short WINDOW of
         upcoming entries in one launch: the ~830 tiny per-layer pack launches of a training step become ~40, while every
         packed weight is still produced just before its consumer (packing everything up front pushes it out of the
@@ -302,7 +321,7 @@ class Tape:
         for j, (w2, a2, wpp) in zip(arr, flat):
             j.w, j.wp, j.Cout, j.Cin, j.KH, j.KW = ptr(w2), wpp, a2[0], a2[1], a2[2], a2[3]
             (j.src_out_major, j.transposed, j.stride, j.pad, j.nonneg, j.bound, j.pedestal, j.src_ld, j.src_off,
-             j.dst_ncot, j.dst_cot_off) = a2[4:15]
+             j.dst_ncot, j.dst_cot_off, j.wino) = a2[4:16]
         e0 = _prof_begin()
         check(L.lib().icm_pack_weights_batch(arr, len(flat), self.st), "pack_weights_batch")
         _prof_end(e0, "pack weights (window)" if len(todo) > 1 else "pack weights (single)", 0.0)
@@ -318,7 +337,7 @@ class Tape:
 
 # ------------------------------------------------------------------------------------------------ raw launches
 def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW, pro_act=ACT_NONE,
-                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0, tag="fwd", seg=None):
+                epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0, tag="fwd", seg=None, algo=0):
     """seg = (run length, gap): blocked input-channel map (icm_conv_args.x_seg_len / x_seg_gap)"""
     a = L.ConvArgs()
     N, _, H, W = x.shape
@@ -335,10 +354,12 @@ def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transpo
     a.accum, a.pixel_shuffle = accum, ps
     if seg is not None:
         a.x_seg_len, a.x_seg_gap = seg
+    a.algo = algo
     check(L.lib().icm_conv_run(C.byref(a), tape.st), "conv_run")
     if e0 is not None:
         px = H * W if transposed else OH * OW
-        _prof_end(e0, _conv_label(tag, transposed, KH, stride, Cin, Cout, H, W, N), 2.0 * N * Cin * Cout * KH * KW * px)
+        _prof_end(e0, _conv_label(tag + ("/wino" if algo else ""), transposed, KH, stride, Cin, Cout, H, W, N),
+                  2.0 * N * Cin * Cout * KH * KW * px)
 
 
 def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
@@ -470,10 +491,12 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
     w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
     if w_as is not None:
         w4 = w.view(w_as[0], w_as[1], 1, 1)
+    wino = 0
     if not transposed:
         Cout, ci, KH, KW = w4.shape
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-        wp = tape.pack(w4, Cout, Cin, KH, KW, 1, 0, stride, pad)
+        wino = 1 if wino_ok(KH, KW, stride, pad, Cin, pixel_shuffle, work=float(N) * OH * OW * Cin * Cout) and w_as is None else 0
+        wp = tape.pack(w4, Cout, Cin, KH, KW, 1, 0, stride, pad, wino=wino)
     else:
         ci, Cout, KH, KW = w4.shape
         OH = (H - 1) * stride - 2 * pad + KH + output_padding
@@ -500,7 +523,7 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
         y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
         tape.mat[_key(y)] = y2
     conv_launch(tape, xf, wp, b, y, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, transposed=transposed,
-                OH=OH, OW=OW, pro_act=actf, epi=epi, res=resv, aux=aux, y2=y2, ps=pixel_shuffle)
+                OH=OH, OW=OW, pro_act=actf, epi=epi, res=resv, aux=aux, y2=y2, ps=pixel_shuffle, algo=wino)
     if not tape.need_grad:
         return y
 
@@ -545,9 +568,12 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             else:
                 raise NotImplementedError("dgrad through this virtual activation")
             if not transposed:   # conv dgrad = scatter with W ([K=Cout][M=Cin])
-                wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad)
+                wb = 2 if (wino_ok(KH, KW, stride, pad, Cout, pixel_shuffle, work=float(N) * H * W * Cin * Cout)
+                           and w_as is None) else 0
+                wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad, wino=wb)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
-                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc, tag="dgrad")
+                            transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc, tag="dgrad",
+                            algo=1 if wb else 0)
             else:                # convT dgrad = gather with Wt ([M=Cin][K=Cout])
                 wpb = tape.pack(w4, Cin, Cout, KH, KW, 1, 0, stride, pad)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
@@ -614,7 +640,7 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,
-                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0, ps=0, tag="fwd"):
+                        pro_act=ACT_NONE, epi=EPI_NONE, auxs=None, y2s=None, ress=None, accum=0, ps=0, tag="fwd", algo=0):
     n = len(xs)
     arr = (L.ConvArgs * n)()
     e0 = _prof_begin()
@@ -633,6 +659,7 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
         res = ress[i] if ress is not None else None
         a.res, a.res_bs = ptr(res), bs(res)
         a.accum, a.pixel_shuffle = accum, ps
+        a.algo = algo
         if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)
                   or bs(y2) != bs(y2s[0] if y2s else None) or bs(res) != bs(ress[0] if ress else None)):
             raise ValueError("grouped conv: members must share strides")
@@ -640,7 +667,7 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
     if e0 is not None:
         N, _, H, W = xs[0].shape
         px = H * W if transposed else OH * OW
-        _prof_end(e0, _conv_label(tag, transposed, KH, stride, Cin, Cout, H, W, N, n),
+        _prof_end(e0, _conv_label(tag + ("/wino" if algo else ""), transposed, KH, stride, Cin, Cout, H, W, N, n),
                   2.0 * n * N * Cin * Cout * KH * KW * px)
 
 
@@ -665,7 +692,8 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
     if ci != Cin:
         raise ValueError("conv2d_group: channel mismatch")
     OH, OW = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
-    wps = [tape.pack(w, Cout, Cin, KH, KW, 1, 0, 1, pad) for w in ws]
+    wino = 1 if wino_ok(KH, KW, 1, pad, Cin, pixel_shuffle, work=float(n) * N * OH * OW * Cin * Cout) else 0
+    wps = [tape.pack(w, Cout, Cin, KH, KW, 1, 0, 1, pad, wino=wino) for w in ws]
     oshape = (N, Cout // 4, OH * 2, OW * 2) if pixel_shuffle == 2 else (N, Cout, OH, OW)
     ys = list(outs) if outs is not None else [new(oshape, x0.device) for _ in range(n)]
     assert all(tuple(y.shape) == oshape for y in ys)
@@ -694,7 +722,7 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
     conv_launch_grouped(tape, xfs, wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
                         transposed=0, OH=OH, OW=OW, pro_act=actf, epi=epi,
                         auxs=list(lrp_auxs) if lrp else None, y2s=y2s,
-                        ress=resf, ps=pixel_shuffle)
+                        ress=resf, ps=pixel_shuffle, algo=wino)
     if not tape.need_grad:
         return ys
 
@@ -751,14 +779,16 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
         else:
             gxs = [torch.empty((N, Cin, H, W), dtype=torch.float32, device=x0.device) for _ in range(n)]
             acc0 = 0
-        wpb = [tape.pack(w, Cin, Cout, KH, KW, 0, 1, 1, pad) for w in ws]
+        wb = 2 if wino_ok(KH, KW, 1, pad, Cout, pixel_shuffle, work=float(n) * N * H * W * Cin * Cout) else 0
+        wpb = [tape.pack(w, Cin, Cout, KH, KW, 0, 1, 1, pad, wino=wb) for w in ws]
         if act == ACT_GELU:
             epi_b = EPI_RES_MUL_DGELU if rgs is not None else EPI_MUL_DGELU
         else:
             epi_b = EPI_RES if rgs is not None else EPI_NONE
         conv_launch_grouped(tape, dys, wpb, None, gxs, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=1, pad=pad,
                             transposed=1, OH=H, OW=W, epi=epi_b,
-                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, ress=rgs, accum=acc0, tag="dgrad")
+                            auxs=[v.t for v in xvs] if act == ACT_GELU else None, ress=rgs, accum=acc0, tag="dgrad",
+                            algo=1 if wb else 0)
         if shared:
             for v, g in zip(xvs, gxs):
                 accumulate(tape, v.t, g)

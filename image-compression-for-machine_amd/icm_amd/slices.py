@@ -130,6 +130,13 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
             tape.bind_grad(Y_hat[:, i * c:(i + 1) * c], dYh[:, i * c:(i + 1) * c], True)
     lib = L.lib()
     conv = dict(KH=KH, KW=KH, stride=1, pad=pad, OH=h, OW=w)
+    px = float(N) * h * w
+
+    def algo(cin, cout, members=1):
+        """(forward pack flag, input-gradient pack flag, launch argument dicts) of a block launch: Winograd when the
+        launch is large enough (engine.wino_ok), else the direct implicit GEMM"""
+        on = E.wino_ok(KH, KH, 1, pad, min(cin, cout), work=px * cin * cout * members)
+        return (1 if on else 0), (2 if on else 0), dict(conv, algo=1 if on else 0)
 
     def done(i, f):
         """pre(i, f) is complete: its consumers read the materialised GELU"""
@@ -142,9 +149,10 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
     srcs = (C.c_void_p * len(order))(*[ptr(B0[k_]) for k_ in order])
     check(lib.icm_gather_vectors(srcs, len(order), D0, ptr(bias0), tape.st), "gather_vectors")
     # slice 0's mean / scale chains have no other block: their first layer is complete (and materialised) here
-    wp0 = [tape.pack_cat([(W0[(0, f)], 0)], D0, M, KH, KH, 1, 0, 1, pad, "M") for f in (0, 2)]
+    wf, _, conv_f = algo(M, D0, 2)
+    wp0 = [tape.pack_cat([(W0[(0, f)], 0)], D0, M, KH, KH, 1, 0, 1, pad, "M", wino=wf) for f in (0, 2)]
     E.conv_launch_grouped(tape, [LM, LSC], wp0, [B0[(0, 0)], B0[(0, 2)]], [pre[(0, 0)], pre[(0, 2)]], Cin=M, Cout=D0,
-                          transposed=0, y2s=[g0[(0, 0)], g0[(0, 2)]] if mat else None, tag="fwd(A0)", **conv)
+                          transposed=0, y2s=[g0[(0, 0)], g0[(0, 2)]] if mat else None, tag="fwd(A0)", **conv_f)
     done(0, 0)
     done(0, 2)
     # everything else: latent_means -> channels [D0, 2*S*D0), latent_scales -> [2*S*D0 + D0, 3*S*D0)
@@ -152,9 +160,10 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
     mem_s = [k_ for k_ in order if k_[1] == 2][1:]
     for xin, mem in ((LM, mem_m), (LSC, mem_s)):
         c0 = off(*mem[0])
-        wpA = tape.pack_cat([(W0[k_], 0) for k_ in mem], D0, M, KH, KH, 1, 0, 1, pad, "M")
+        wf, _, conv_f = algo(M, len(mem) * D0)
+        wpA = tape.pack_cat([(W0[k_], 0) for k_ in mem], D0, M, KH, KH, 1, 0, 1, pad, "M", wino=wf)
         E.conv_launch(tape, xin, wpA, bias0[c0:c0 + len(mem) * D0], PRE0[:, c0:c0 + len(mem) * D0], Cin=M,
-                      Cout=len(mem) * D0, transposed=0, tag="fwd(A)", **conv)
+                      Cout=len(mem) * D0, transposed=0, tag="fwd(A)", **conv_f)
     if need:
         def bwd_A():
             # weight (+ bias) gradients of the latent blocks: 3*S problems of one geometry, columns [0, M) of each weight
@@ -168,10 +177,11 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
                 if not tape.wants(xin):
                     continue
                 c0 = off(*mem[0])
-                wpb = tape.pack_cat([(W0[k_], 0) for k_ in mem], M, D0, KH, KH, 0, 1, 1, pad, "K")
+                _, wbk, conv_b = algo(len(mem) * D0, M)
+                wpb = tape.pack_cat([(W0[k_], 0) for k_ in mem], M, D0, KH, KH, 0, 1, 1, pad, "K", wino=wbk)
                 gx, acc = tape.grad_for_write(xin)
                 E.conv_launch(tape, DPRE0[:, c0:c0 + len(mem) * D0], wpb, None, gx, Cin=len(mem) * D0, Cout=M,
-                              transposed=1, accum=acc, tag="dgrad(A)", **conv)
+                              transposed=1, accum=acc, tag="dgrad(A)", **conv_b)
         tape.bw.append(bwd_A)
 
     # ---------------------------------------------------------------------------------------------- B / C helpers
@@ -181,11 +191,12 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
         n = len(idx)
         sup = Y_hat[:, :c * k]
         r0 = [off(idx[0], f) for f in range(3)]
-        wps = [tape.pack_cat([(W0[(i, f)], M) for i in idx], D0, c * k, KH, KH, 1, 0, 1, pad, "M") for f in range(3)]
+        wf, _, conv_f = algo(c * k, n * D0, 3)
+        wps = [tape.pack_cat([(W0[(i, f)], M) for i in idx], D0, c * k, KH, KH, 1, 0, 1, pad, "M", wino=wf) for f in range(3)]
         ys = [PRE0[:, r:r + n * D0] for r in r0]
         y2s = [G0[:, r:r + n * D0] for r in r0] if mat else None
         E.conv_launch_grouped(tape, [sup] * 3, wps, None, ys, Cin=c * k, Cout=n * D0, transposed=0, y2s=y2s, accum=1,
-                              tag="fwd(B)", **conv)
+                              tag="fwd(B)", **conv_f)
         for i in idx:
             done(i, 0)
             done(i, 2)
@@ -197,19 +208,22 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
                         E.wgrad_defer(tape, DPRE0[:, off(i, f):off(i, f) + D0], sup, gw[:, M:M + c * k], Ca=D0, Cb=c * k,
                                       KH=KH, KW=KH, stride=1, pad=pad, accum=1, dw_ld=W0[(i, f)].shape[1])
                 # d y_hat[:, :c*k] += sum over the 3*n chains: one contraction, channels (f, i) picked by the blocked map
-                wpb = tape.pack_cat([(W0[(i, f)], M) for f in range(3) for i in idx], c * k, D0, KH, KH, 0, 1, 1, pad, "K")
+                _, wbk, conv_b = algo(3 * n * D0, c * k)
+                wpb = tape.pack_cat([(W0[(i, f)], M) for f in range(3) for i in idx], c * k, D0, KH, KH, 0, 1, 1, pad, "K",
+                                    wino=wbk)
                 gx, acc = tape.grad_for_write(sup)
                 E.conv_launch(tape, DPRE0[:, r0[0]:], wpb, None, gx, Cin=3 * n * D0, Cout=c * k, transposed=1, accum=acc,
-                              seg=(n * D0, (S - n) * D0), tag="dgrad(B)", **conv)
+                              seg=(n * D0, (S - n) * D0), tag="dgrad(B)", **conv_b)
             tape.bind_grad(sup, dYh[:, :c * k], True)
             tape.bw.append(bwd_B)
 
     def own_block(idx, k):
         """C: y_hat_pre of slice i (c channels) into the first layer of its lrp chain (cnn.py:174), completing it"""
         xs = [YP[:, i * c:(i + 1) * c] for i in idx]
-        wps = [tape.pack_cat([(W0[(i, 1)], M + c * k)], D0, c, KH, KH, 1, 0, 1, pad, "M") for i in idx]
+        wf, _, conv_f = algo(c, D0, len(idx))
+        wps = [tape.pack_cat([(W0[(i, 1)], M + c * k)], D0, c, KH, KH, 1, 0, 1, pad, "M", wino=wf) for i in idx]
         E.conv_launch_grouped(tape, xs, wps, None, [pre[(i, 1)] for i in idx], Cin=c, Cout=D0, transposed=0,
-                              y2s=[g0[(i, 1)] for i in idx] if mat else None, accum=1, tag="fwd(C)", **conv)
+                              y2s=[g0[(i, 1)] for i in idx] if mat else None, accum=1, tag="fwd(C)", **conv_f)
         for i in idx:
             done(i, 1)
         if need:
@@ -223,9 +237,10 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
                     if not acc:          # (the LRP tail's identity path wrote it first; a launch has one accumulate flag)
                         gx.zero_()
                     gxs.append(gx)
-                wpb = [tape.pack_cat([(W0[(i, 1)], M + c * k)], c, D0, KH, KH, 0, 1, 1, pad, "K") for i in idx]
+                _, wbk, conv_b = algo(D0, c, len(idx))
+                wpb = [tape.pack_cat([(W0[(i, 1)], M + c * k)], c, D0, KH, KH, 0, 1, 1, pad, "K", wino=wbk) for i in idx]
                 E.conv_launch_grouped(tape, [DPRE0[:, off(i, 1):off(i, 1) + D0] for i in idx], wpb, None, gxs, Cin=D0,
-                                      Cout=c, transposed=1, accum=1, tag="dgrad(C)", **conv)
+                                      Cout=c, transposed=1, accum=1, tag="dgrad(C)", **conv_b)
             tape.bw.append(bwd_C)
 
     def gauss(idx):

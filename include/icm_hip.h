@@ -78,7 +78,16 @@ typedef struct icm_conv_args {
    * K-concatenation of equally long channel runs that lie x_seg_len + x_seg_gap planes apart (the first-layer input
    * gradients of all slice chains of one family, cnn.py:89-127, contracted in ONE launch) */
   int x_seg_len, x_seg_gap;
+  /* ICM_ALGO_DIRECT (0): implicit GEMM over the spatial taps.  ICM_ALGO_WINOGRAD (1): F(2x2, 3x3) -- 3x3 stride-1 pad-1
+   * launches only (icm_conv_winograd_ok), forward or input gradient; wp must then hold the Winograd-domain weights
+   * (icm_pack_job.wino: 1 for the forward orientation, 2 for the input-gradient orientation).  Same f32 arithmetic
+   * type, 4/9 of the multiply-adds; results agree with the direct form to summation-order noise. */
+  int algo;
 } icm_conv_args;
+#define ICM_ALGO_DIRECT 0
+#define ICM_ALGO_WINOGRAD 1
+/* 1 if icm_conv_run accepts these arguments with algo = ICM_ALGO_WINOGRAD (geometry and epilogue kind supported) */
+int icm_conv_winograd_ok(const icm_conv_args* a);
 
 int icm_conv_run(const icm_conv_args* a, void* stream);
 /* up to 3 problems of identical geometry in one launch (cc_mean || cc_scale chains, cnn.py:164-168) */
@@ -112,6 +121,11 @@ typedef struct icm_pack_job {
    * this job's tiles start at dst_cot_off.  (Concatenation along GEMM-K needs no field: consecutive jobs write
    * consecutive chunk ranges, i.e. wp advanced by icm_packed_weight_floats of the preceding jobs.) */
   int dst_ncot, dst_cot_off;
+  /* 0: spatial taps (in the order transposed / stride / pad select).  1 / 2: Winograd F(2x2,3x3) weights G g G^T of a
+   * 3x3 stride-1 pad-1 kernel, 16 transform points per (Cout, Cin) pair: 1 = forward orientation, 2 = input-gradient
+   * orientation (kernel rotated by 180 degrees; pass the transposed matrix roles as for the direct dgrad pack).
+   * Buffer size: icm_packed_weight_floats(Cout, Cin, 4, 4). */
+  int wino;
 } icm_pack_job;
 int icm_pack_weights_batch(const icm_pack_job* jobs, int n, void* stream);
 
@@ -348,6 +362,9 @@ int icm_pad2d(const float* src, int N, int C, int H, int W, float* dst, int OH, 
  * 5x5 form; 11-14 the DMA-only 1x1 kernel <6,6> / <3,6> / <6,3> / <3,3>; -1 = automatic) and its XCD-aware
  * workgroup order (0 / 1, -1 = automatic) */
 void icm_debug_force_conv_cfg(int idx);
+/* the value last set (-1 = automatic): callers that choose between the direct and the Winograd form keep the direct
+ * one while a tile configuration is forced */
+int icm_debug_forced_conv_cfg(void);
 /* pointwise (1x1 stride-1, Cin % 8 == 0) convolutions: -1 = automatic (the barrier-free direct-operand kernel when the
  * launch has >= 1024 waves), 0 = always the LDS-staged kernel, 1 = the direct kernel whenever eligible */
 void icm_debug_force_conv1x1(int mode);

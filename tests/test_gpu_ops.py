@@ -945,3 +945,104 @@ def test_grouped_conv_rejects_mismatching_members():
         bad = (L.ConvArgs * 2)(arg(), arg(**over))
         assert L.lib().icm_conv_run_grouped(bad, 2, L.stream()) == 1, over
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------ Winograd F(2x2, 3x3)
+WINO_CASES = [
+    # name, N, Cin, H, W, Cout
+    ("w_chain_224_176", 16, 224, 16, 16, 176),
+    ("w_ru_96_96", 2, 96, 64, 64, 96),
+    ("w_odd_40_72", 3, 40, 11, 13, 72),          # odd sizes: partial 2x2 tiles, channels not a multiple of 16 / 32
+    ("w_tiny_192_192", 16, 192, 4, 4, 192),
+    ("w_64_32", 16, 64, 16, 16, 32),
+    ("w_24_200", 2, 24, 20, 36, 200),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_winograd_conv_vs_torch_and_direct(case, monkeypatch):
+    """csrc/conv_wino.hip through engine.conv2d: forward (bias, materialised GELU) and input gradient (GELU' epilogue,
+    accumulation) of 3x3 stride-1 pad-1 convolutions against torch on the CPU, and against the direct implicit-GEMM
+    kernel on the same inputs (the two algorithms must agree to summation-order noise)."""
+    from icm_amd import engine as E
+    from icm_amd.engine import VT
+    _, N, Cin, H, Wd, Cout = case
+    d = dev()
+    x = U(case[0] + ".x", (N, Cin, H, Wd), -1.5, 1.5)
+    w = U(case[0] + ".w", (Cout, Cin, 3, 3), -0.2, 0.2)
+    b = U(case[0] + ".b", (Cout,), -0.5, 0.5)
+    g = U(case[0] + ".g", (N, Cout, H, Wd), -1.0, 1.0)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(F.gelu(xr), w, b, padding=1)
+    yr.backward(g)
+    outs = {}
+    monkeypatch.setattr(E, "_MAT_MIN_PIXELS", 0)
+    monkeypatch.setattr(E, "_WINO_MIN_WORK", 0.0)     # (by default small launches stay on the direct kernels)
+    for name, on in (("wino", True), ("direct", False)):
+        monkeypatch.setattr(E, "USE_WINO", on)
+        assert E.wino_ok(3, 3, 1, 1, Cin) == on
+        tape = E.Tape(need_grad=True)
+        xd = x.to(d)
+        wd_, bd = w.to(d), b.to(d)
+        y = E.conv2d(tape, VT(xd, E.ACT_GELU), wd_, bd, pad=1, act_out=True)       # virtual-GELU operand
+        y2 = tape.mat[E._key(y)]
+        tape.bind_grad(y, g.to(d), True)
+        gx0 = torch.full_like(xd, 0.25)
+        tape.bind_grad(xd, gx0, True)                                             # dgrad accumulates onto 0.25
+        tape.backward()
+        torch.cuda.synchronize()
+        outs[name] = (y, y2, tape.grad_of(xd), tape.grad_of(wd_), tape.grad_of(bd))
+        close(y, yr, what=name + " fwd")
+        close(y2, F.gelu(yr), what=name + " gelu(fwd)")
+        close(tape.grad_of(xd) - 0.25, xr.grad, tol=5e-5, what=name + " dgrad")
+    # algorithm against algorithm: tighter than either against the CPU
+    close(outs["wino"][0], outs["direct"][0], tol=1e-5, what="wino vs direct fwd")
+    close(outs["wino"][2], outs["direct"][2], tol=2e-5, what="wino vs direct dgrad")
+    assert torch.equal(outs["wino"][3], outs["direct"][3])    # the weight gradient is the same (direct) kernel
+
+
+def test_winograd_grouped_lrp_residual_and_blocked_map(monkeypatch):
+    """fused neighbours of the Winograd epilogue (residual, LRP tanh with its second output, in-place accumulation +
+    materialisation) in grouped launches, and the blocked input-channel map, against the direct kernel"""
+    from icm_amd import engine as E
+    d = dev()
+    N, Cin, H, Wd, Cout = 4, 64, 16, 16, 32
+    xs = [U(f"wg.x{i}", (N, Cin, H, Wd)).to(d) for i in range(3)]
+    ws = [U(f"wg.w{i}", (Cout, Cin, 3, 3), -0.2, 0.2).to(d) for i in range(3)]
+    bs_ = [U(f"wg.b{i}", (Cout,)).to(d) for i in range(3)]
+    aux = [U(f"wg.a{i}", (N, Cout, H, Wd)).to(d) for i in range(3)]
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(E, "USE_WINO", on)
+        tape = E.Tape(need_grad=False)
+        wino = 1 if on else 0
+        wps = [tape.pack(w, Cout, Cin, 3, 3, 1, 0, 1, 1, wino=wino) for w in ws]
+        kw = dict(Cin=Cin, Cout=Cout, KH=3, KW=3, stride=1, pad=1, transposed=0, OH=H, OW=Wd, algo=wino)
+        y_lrp = [torch.empty((N, Cout, H, Wd), device=d) for _ in range(3)]
+        t_lrp = [torch.empty((N, Cout, H, Wd), device=d) for _ in range(3)]
+        E.conv_launch_grouped(tape, xs, wps, bs_, y_lrp, epi=E.EPI_LRP, auxs=aux, y2s=t_lrp, **kw)
+        y_res = [torch.empty((N, Cout, H, Wd), device=d) for _ in range(3)]
+        E.conv_launch_grouped(tape, xs, wps, bs_, y_res, epi=E.EPI_RES_GELU, ress=aux, **kw)
+        y_acc = [a.clone() for a in aux]
+        g_acc = [torch.empty((N, Cout, H, Wd), device=d) for _ in range(3)]
+        E.conv_launch_grouped(tape, xs, wps, None, y_acc, y2s=g_acc, accum=1, **kw)
+        # blocked map: the 64 input channels as two runs of 32 lying 96 planes apart
+        wide = torch.full((N, 128 + 32, H, Wd), float("nan"), device=d)
+        wide[:, :32] = xs[0][:, :32]
+        wide[:, 128:] = xs[0][:, 32:]
+        y_seg = torch.empty((N, Cout, H, Wd), device=d)
+        E.conv_launch(tape, wide, wps[0], bs_[0], y_seg, seg=(32, 96), **kw)
+        torch.cuda.synchronize()
+        res[on] = (y_lrp, t_lrp, y_res, y_acc, g_acc, y_seg)
+    for i in range(3):
+        ref = F.conv2d(xs[i].cpu(), ws[i].cpu(), bs_[i].cpu(), padding=1)
+        close(res[True][0][i], aux[i].cpu() + 0.5 * torch.tanh(ref), what="lrp")
+        close(res[True][1][i], torch.tanh(ref), what="lrp tanh")
+        close(res[True][2][i], ref + F.gelu(aux[i].cpu()), what="res_gelu")
+        acc_ref = F.conv2d(xs[i].cpu(), ws[i].cpu(), None, padding=1) + aux[i].cpu()
+        close(res[True][3][i], acc_ref, what="accumulate")
+        close(res[True][4][i], F.gelu(acc_ref), what="gelu(accumulate)")
+        for k in range(5):
+            close(res[True][k][i], res[False][k][i], tol=1e-5, what=f"wino vs direct {k}")
+    close(res[True][5], F.conv2d(xs[0].cpu(), ws[0].cpu(), bs_[0].cpu(), padding=1), what="blocked map")
+    close(res[True][5], res[False][5], tol=1e-5, what="blocked map wino vs direct")
