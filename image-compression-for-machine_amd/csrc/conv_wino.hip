@@ -37,6 +37,8 @@ struct WinoDesc {
   int epi, accum, act;
   int seg_len, seg_gap;
   FastDiv dseg;
+  int dbg;            // measurement only (ICM_WINO_DEBUG): 1 = no patch loads, 2 = no weight loads in the loop, 4 = no stores,
+                      // 8 = no input transform / LDS stores, 16 = no B-fragment LDS reads
   int px_fast, npx;   // workgroup order: pixel blocks fastest (weights stationary per XCD) when the weights outweigh the activations
 };
 
@@ -116,10 +118,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 4; ++dx)
-            r[k][dy * 4 + dx] = (cok && ((mask >> (dy * 4 + dx)) & 1u)) ? pc[dy * d.W + dx] : 0.0f;
+            r[k][dy * 4 + dx] = (cok && ((mask >> (dy * 4 + dx)) & 1u) && !(d.dbg & 1)) ? pc[dy * d.W + dx] : 0.0f;
       }
     };
     auto transform_store = [&](const float (&r)[2][16], int buf) {
+      if (d.dbg & 8) return;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         float dd[16], u[16];
@@ -142,18 +145,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
         }
       }
     };
-    float ra[2][16], rb[2][16];
+    // three register sets: the gather loads of step s + 3 are issued while step s is multiplied and step s + 1 is
+    // transformed -- two full steps (~8 000 cycles) of latency budget (HBM misses under load take 3-5 us; with one
+    // step of slack the MFMA waves waited at the barrier: measured -15 % on the wide first-layer launches)
+    float ra[2][16], rb[2][16], rc[2][16];
     load(ra, 0);
     if (d.nsteps > 1) load(rb, 1);
+    if (d.nsteps > 2) load(rc, 2);
     transform_store(ra, 0);
     __syncthreads();   // step 0 published
-    for (int s = 0; s < d.nsteps; s += 2) {
-      if (s + 2 < d.nsteps) load(ra, s + 2);
-      if (s + 1 < d.nsteps) transform_store(rb, 1);
+    for (int s = 0; s < d.nsteps; s += 3) {
+      // step s is being multiplied (buffer s & 1); produce step s + 1 into the other buffer
+      if (s + 3 < d.nsteps) load(ra, s + 3);
+      if (s + 1 < d.nsteps) transform_store(rb, (s + 1) & 1);
       __syncthreads();
       if (s + 1 >= d.nsteps) break;
-      if (s + 3 < d.nsteps) load(rb, s + 3);
-      if (s + 2 < d.nsteps) transform_store(ra, 0);
+      if (s + 4 < d.nsteps) load(rb, s + 4);
+      if (s + 2 < d.nsteps) transform_store(rc, (s + 2) & 1);
+      __syncthreads();
+      if (s + 2 >= d.nsteps) break;
+      if (s + 5 < d.nsteps) load(rc, s + 5);
+      if (s + 3 < d.nsteps) transform_store(ra, (s + 3) & 1);
       __syncthreads();
     }
   } else {
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
       if (u + 1 < 8) {   // next unit's B fragment (same step: same buffer)
         const float* nb = vb + ((u + 1) >> 2) * (16 * 256) + ((u + 1) & 3) * 256;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[(u + 1) & 1][j] = nb[j * 64];
+        for (int j = 0; j < 4; ++j) bv[(u + 1) & 1][j] = (d.dbg & 16) ? 1.0f : nb[j * 64];
       }
       const char* sp = wptr(min(g + 3, nunits - 1));
 #pragma unroll
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[u & 3][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u & 3][a][j], bv[u & 1][j], acc[u & 3][a], 0, 0, 0);
-        aq[(u + 3) & 3][a] = *reinterpret_cast<const f32x4*>(sp + wl[a]);
+        if (!(d.dbg & 2)) aq[(u + 3) & 3][a] = *reinterpret_cast<const f32x4*>(sp + wl[a]);
       }
     }
     __syncthreads();
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
       }
     }
   };
+  if (d.dbg & 4) return;
   switch (d.epi) {
     case ICM_EPI_RES: finish_all(std::integral_constant<int, ICM_EPI_RES>{}); break;
     case ICM_EPI_RES_GELU: finish_all(std::integral_constant<int, ICM_EPI_RES_GELU>{}); break;
@@ -318,6 +331,8 @@ int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
   }
   d.ncb = cdiv(d.ncot, tco);
   d.npx = (int)pblocks;
+  static const int dbg = getenv("ICM_WINO_DEBUG") ? atoi(getenv("ICM_WINO_DEBUG")) : 0;
+  d.dbg = dbg;
   {
     const double wbytes = 64.0 * a.Cin * a.Cout, abytes = 4.0 * a.Cin * a.N * a.H * a.W;
     static const int force_order = getenv("ICM_WINO_PXFAST") ? atoi(getenv("ICM_WINO_PXFAST")) : -1;

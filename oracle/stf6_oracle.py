@@ -80,9 +80,10 @@ def hyper_slices_zigzag(y: Tensor, sd, noise, drops, round_override=None):
             t, _, _ = S.basic_layer(t, hb, wb, sd, f"mu_Swin.{i}.{l}", RDEPTHS[l], MU_HEADS, S.WINDOW, None, drops)
         mu = mu + t.view(-1, hb, wb, cs).permute(0, 3, 1, 2).contiguous()
         ys = y_zz[:, i]
-        _, lik = O.gaussian_likelihood(ys, sc, mu, None if noise is None else noise["y"][:, i])
+        ry = ro["y"][:, i] if "y" in ro else None
+        _, lik = O.gaussian_likelihood(ys, sc, mu, None if noise is None else noise["y"][:, i], round_to=ry)
         liks.append(lik)
-        yh = O.ste_round_as(ys - mu, ro["y"][:, i] if "y" in ro else None) + mu
+        yh = O.ste_round_as(ys - mu, ry) + mu
         lrp = O._seq_convs(torch.cat([mean_sup, yh], 1), sd, f"lrp_transforms2.{i}", (0, 2, 4, 6, 8))
         yh = yh + 0.5 * torch.tanh(lrp)
         y_hat_slices.append(yh)

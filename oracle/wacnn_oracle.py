@@ -216,10 +216,14 @@ def eb_aux_loss(sd, p: str = "entropy_bottleneck", tail_mass: float = 1e-9) -> T
     return torch.abs(logits - target).sum()
 
 
-def gaussian_likelihood(y: Tensor, scales: Tensor, means: Tensor, noise: Optional[Tensor] = None):
-    """GaussianConditional.forward -> (y_tilde, likelihood). entropy_models.py:578-582,626-659."""
+def gaussian_likelihood(y: Tensor, scales: Tensor, means: Tensor, noise: Optional[Tensor] = None,
+                        round_to: Optional[Tensor] = None):
+    """GaussianConditional.forward -> (y_tilde, likelihood). entropy_models.py:578-582,626-659.
+    round_to (tests only, eval mode): adopt these rounding decisions round(y - means) instead of taking them here, so
+    that a latent within float noise of a half-integer yields the likelihood of the symbol the checked implementation
+    coded (flips are counted separately by the tests)."""
     if noise is None:
-        out = torch.round(y - means) + means
+        out = (torch.round(y - means) if round_to is None else round_to.to(y.dtype)) + means
     else:
         out = y + noise
     s = lower_bound(scales, SCALE_BOUND)
@@ -363,9 +367,9 @@ def hyper_slices(y: Tensor, sd: Dict[str, Tensor], noise: Optional[Dict[str, Ten
         scale_sup = torch.cat([lat_scales] + sup, 1)
         sc = _seq_convs(scale_sup, sd, f"cc_scale_transforms.{i}", (0, 2, 4, 6, 8))
         sc = sc[:, :, :y.shape[2], :y.shape[3]]
-        _, lik = gaussian_likelihood(ys, sc, mu, None if noise is None else n_slices[i])
-        liks.append(lik)
         ry = ro["y"].chunk(num_slices, 1)[i] if "y" in ro else None
+        _, lik = gaussian_likelihood(ys, sc, mu, None if noise is None else n_slices[i], round_to=ry)
+        liks.append(lik)
         yh = ste_round_as(ys - mu, ry) + mu
         lrp = _seq_convs(torch.cat([mean_sup, yh], 1), sd, f"lrp_transforms.{i}", (0, 2, 4, 6, 8))
         yh = yh + 0.5 * torch.tanh(lrp)
