@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
 objs=""
 pids=""
-for f in conv_igemm conv_1x1 conv_ks8 conv_wino conv_wgrad pointwise entropy winattn winattn_mfma; do
+for f in conv_igemm conv_1x1 conv_ks8 conv_wino conv_wgrad wgrad_wino pointwise entropy winattn winattn_mfma; do
   stale=0
   for dep in csrc/$f.hip csrc/icm_common.h ../include/icm_hip.h $(grep -q conv_common.h csrc/$f.hip && echo csrc/conv_common.h); do
     if [ ! -f build/$f.o ] || [ $dep -nt build/$f.o ]; then stale=1; fi

@@ -21,6 +21,11 @@ namespace icm {
 
 #define WG_MAX_TAPS 32
 
+// Winograd F(2x2, 3x3) form (wgrad_wino.hip): writes dU slabs [split][16][a][b] (+ bias partials [split][a])
+int wgrad_wino_plan(const icm_wgrad_args& a, int nproblems, int* nsplit_out, int* nchunks_out);
+int launch_wgrad_wino(const icm_wgrad_args* arr, int n, int nsplit, int nchunks, float* const* ws, float* const* dbias_ws,
+                      hipStream_t stream);
+
 #define WG_MAXG 32
 struct WgPtrs {
   const float* gs;
@@ -784,6 +789,7 @@ struct RedPtrs {
 struct RedDesc {
   RedPtrs g[WG_MAXG];
   int Ca, Cb, ntaps, nsplit, nsplit_bias, nwblocks, vec4;
+  int wino;   // the slabs hold Winograd-domain gradients dU[16][a][b] (wgrad_wino.hip): ntaps = 16 in, dW = G^T dU G (9 taps) out
 };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   __shared__ __attribute__((aligned(16))) float tile[WG_MAX_TAPS][257];
@@ -873,6 +879,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedDesc d) {
   }
   __syncthreads();
   const int nv = (int)min((long long)64, CaCb - ab0);
+  if (d.wino) {
+    // dW[p][q] = sum_ij G[i][p] dU[i][j] G[j][q],  G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]  (linear: applied
+    // once, after the pixel splits have been added)
+    for (int e = threadIdx.x; e < nv * 9; e += 256) {
+      const int abl = e / 9, t = e - abl * 9;
+      const int p = t / 3, q = t - p * 3;
+      float col[4];   // (dU G)[i][q]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float u0 = tile[i * 4 + 0][abl], u1 = tile[i * 4 + 1][abl], u2 = tile[i * 4 + 2][abl], u3 = tile[i * 4 + 3][abl];
+        col[i] = q == 0 ? u0 + 0.5f * (u1 + u2) : (q == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3);
+      }
+      float v = p == 0 ? col[0] + 0.5f * (col[1] + col[2]) : (p == 1 ? 0.5f * (col[1] - col[2]) : 0.5f * (col[1] + col[2]) + col[3]);
+      const long long abg = ab0 + abl, ar = abg / d.Cb;
+      float* o = G.dw + (ar * G.dw_ld + (abg - ar * d.Cb)) * 9 + t;
+      if (G.accum) v += *o;
+      *o = v;
+    }
+    return;
+  }
   if (G.dw_ld == d.Cb) {
     float* o = G.dw + ab0 * ntaps;
     for (int e = threadIdx.x; e < nv * ntaps; e += 256) {
@@ -1089,6 +1115,11 @@ extern "C" {
 
 int64_t icm_wgrad_workspace_floats_grouped(const icm_wgrad_args* a, int n) {
   icm::WgPlan p;
+  if (a && n >= 1 && a->algo == ICM_ALGO_WINOGRAD) {
+    int nsplit = 0, nchunks = 0;
+    if (!a->gs || !a->gb || a->N <= 0 || a->Ca <= 0 || a->Cb <= 0 || icm::wgrad_wino_plan(*a, n, &nsplit, &nchunks)) return -1;
+    return (int64_t)nsplit * 16 * a->Ca * a->Cb + (int64_t)nsplit * a->Ca;
+  }
   if (!a || n < 1 || icm::plan_wgrad(*a, p, n)) return -1;
   return (int64_t)p.nsplit * a->KH * a->KW * a->Ca * a->Cb + (int64_t)p.nsplit * a->Ca;
 }
@@ -1098,6 +1129,46 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   using namespace icm;
   if (!arr || n < 1 || n > WG_MAXG) return ICM_ERR_ARG;
   const icm_wgrad_args* a = &arr[0];
+  if (a->algo == ICM_ALGO_WINOGRAD) {
+    int nsplit = 0, nchunks = 0;
+    if (!a->gs || !a->gb || a->N <= 0 || a->Ca <= 0 || a->Cb <= 0) return ICM_ERR_ARG;
+    int rcw = wgrad_wino_plan(*a, n, &nsplit, &nchunks);
+    if (rcw) return rcw;
+    if ((long long)a->N * ((a->W + 1) / 2) * ((a->H + 1) / 2) >= 65536) return ICM_ERR_UNSUPPORTED;   // tile index fits the fast division
+    const long long slab_all = (long long)nsplit * 16 * a->Ca * a->Cb;
+    float* wsp[WG_MAXG];
+    float* dbp[WG_MAXG];
+    RedDesc r{};
+    for (int i = 0; i < n; ++i) {
+      const icm_wgrad_args& b = arr[i];
+      if (!b.gs || !b.gb || !b.dw || !b.ws) return ICM_ERR_ARG;
+      if (b.Ca != a->Ca || b.Cb != a->Cb || b.OH != a->OH || b.OW != a->OW || b.H != a->H || b.W != a->W || b.N != a->N ||
+          b.KH != a->KH || b.KW != a->KW || b.stride != a->stride || b.pad != a->pad || b.act_s != a->act_s ||
+          b.act_b != a->act_b || b.gs_bs != a->gs_bs || b.gb_bs != a->gb_bs || b.algo != a->algo)
+        return ICM_ERR_ARG;
+      if (b.ws_floats > 0 && b.ws_floats < slab_all + (long long)nsplit * a->Ca) return ICM_ERR_ARG;
+      wsp[i] = b.ws;
+      dbp[i] = b.dbias ? b.ws + slab_all : nullptr;
+    }
+    rcw = launch_wgrad_wino(arr, n, nsplit, nchunks, wsp, dbp, stream);
+    if (rcw) return rcw;
+    bool any_bias = false;
+    for (int i = 0; i < WG_MAXG; ++i) {
+      const icm_wgrad_args& b = arr[i < n ? i : 0];
+      r.g[i].ws = b.ws; r.g[i].dw = b.dw; r.g[i].dbias_ws = b.dbias ? b.ws + slab_all : nullptr; r.g[i].dbias = b.dbias;
+      r.g[i].accum = b.accum; r.g[i].accum_bias = b.accum_bias;
+      r.g[i].dw_ld = b.dw_ld > 0 ? b.dw_ld : a->Cb;
+      if (r.g[i].dw_ld < a->Cb) return ICM_ERR_ARG;
+      if (i < n) any_bias |= b.dbias != nullptr;
+    }
+    r.Ca = a->Ca; r.Cb = a->Cb; r.ntaps = 16; r.nsplit = nsplit; r.nsplit_bias = nsplit; r.vec4 = 0; r.wino = 1;
+    r.nwblocks = (int)(((long long)a->Ca * a->Cb + 63) / 64);
+    const int rblocks = r.nwblocks + (any_bias ? cdiv(a->Ca, 16) : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks, n), dim3(256), 0, stream, r);
+    ICM_CHECK_LAUNCH();
+    return ICM_OK;
+  }
+  if (a->algo != ICM_ALGO_DIRECT) return ICM_ERR_ARG;
   WgPlan p;
   int rc = plan_wgrad(*a, p, n);
   if (rc) return rc;
@@ -1106,7 +1177,7 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
     if (!b.gs || !b.gb || !b.dw || !b.ws) return ICM_ERR_ARG;
     if (b.Ca != a->Ca || b.Cb != a->Cb || b.OH != a->OH || b.OW != a->OW || b.H != a->H || b.W != a->W ||
         b.N != a->N || b.KH != a->KH || b.KW != a->KW || b.stride != a->stride || b.pad != a->pad ||
-        b.act_s != a->act_s || b.act_b != a->act_b || b.gs_bs != a->gs_bs || b.gb_bs != a->gb_bs)
+        b.act_s != a->act_s || b.act_b != a->act_b || b.gs_bs != a->gs_bs || b.gb_bs != a->gb_bs || b.algo != a->algo)
       return ICM_ERR_ARG;
   }
   if (((long long)a->N * a->gb_bs + 8LL * a->H * a->W) * 4 >= (1LL << 31)) return ICM_ERR_UNSUPPORTED;   // PlaneMap byte offsets are int32

@@ -38,7 +38,7 @@ class WgradArgs(C.Structure):
         ("gb", vp), ("gb_bs", i64), ("Cb", i32), ("H", i32), ("W", i32), ("act_b", i32),
         ("N", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32),
         ("dw", vp), ("ws", vp), ("accum", i32),
-        ("dbias", vp), ("accum_bias", i32), ("ws_floats", i64), ("dw_ld", i32),
+        ("dbias", vp), ("accum_bias", i32), ("ws_floats", i64), ("dw_ld", i32), ("algo", i32),
     ]
 
 

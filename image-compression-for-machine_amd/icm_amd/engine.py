@@ -36,6 +36,9 @@ _WINO_MIN_CIN = int(_os.environ.get("ICM_WINO_MIN_CIN", "16"))
 # many multiply-adds of the DIRECT form per launch / 9 (N * H * W * Cin * Cout * members) the direct kernels win
 # (measured on MI355X, profiles/r03_wino_vs_direct.txt)
 _WINO_MIN_WORK = float(_os.environ.get("ICM_WINO_MIN_WORK", "2.0e8"))
+# weight gradients are issued in batches of same-geometry problems (flush_wgrads): a single problem counts this many times
+_WINO_WG_BATCH = float(_os.environ.get("ICM_WINO_WG_BATCH", "4"))
+USE_WINO_WGRAD = _os.environ.get("ICM_WINO_WGRAD", "1") != "0"
 _WINO_EPIS = (EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_MUL_DGELU, EPI_RES_MUL_DGELU, EPI_LRP)
 
 
@@ -384,13 +387,17 @@ def wgrad_launch(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NON
 
 
 def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE, act_b=ACT_NONE, accum=0,
-                dbias=None, accum_bias=0, dw_ld=0):
+                dbias=None, accum_bias=0, dw_ld=0, algo=None):
     """Queue a weight-gradient problem.  Nothing but the optimiser consumes a weight gradient, so problems are
     collected while the tape unwinds and issued in batches of identical geometry (flush_wgrads).
     dw_ld > 0: dw points at a column block of a [Ca][dw_ld][KH][KW] tensor (icm_wgrad_args.dw_ld)."""
     N, _, OH, OW = gs.shape
     _, _, H, W = gb.shape
-    key = (Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, bs(gs), bs(gb), dbias is not None)
+    if algo is None:   # Winograd form for 3x3 stride-1 problems (wgrad_wino.hip); the work of a batch is what counts, so the
+        #                threshold is applied per problem with a typical batch factor folded into ICM_WINO_MIN_WORK_WG
+        algo = 1 if (USE_WINO_WGRAD and wino_ok(KH, KW, stride, pad, min(Ca, Cb), work=float(N) * OH * OW * Ca * Cb * _WINO_WG_BATCH)
+                     and N * ((OH + 1) // 2) * ((OW + 1) // 2) < 65536) else 0
+    key = (Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, bs(gs), bs(gb), dbias is not None, algo)
     tape.wjobs.append((key, gs, gb, dw, accum, dbias, accum_bias, dw_ld))
 
 
@@ -418,7 +425,7 @@ def flush_wgrads(tape):
         st = side.cuda_stream
         tape._flushed.append(jobs_all)
     for key, jobs in groups.items():
-        Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, gsb, gbb, _ = key
+        Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, gsb, gbb, _, algo = key
         for i0 in range(0, len(jobs), 32):
             chunk = jobs[i0:i0 + 32]
             arr = (L.WgradArgs * len(chunk))()
@@ -429,6 +436,7 @@ def flush_wgrads(tape):
                 a.dw, a.accum = ptr(dw), accum
                 a.dbias, a.accum_bias = ptr(dbias), accum_bias
                 a.dw_ld = dw_ld
+                a.algo = algo
             n = lib.icm_wgrad_workspace_floats_grouped(C.byref(arr[0]), len(chunk))
             if n < 0:
                 raise ValueError("icm wgrad: invalid geometry")
@@ -445,7 +453,7 @@ def flush_wgrads(tape):
                 a.ws, a.ws_floats = ptr(ws) + 4 * n * j, n
             e0 = _prof_begin(side)
             check(lib.icm_conv_wgrad_grouped(arr, len(chunk), st), "conv_wgrad_grouped")
-            _prof_end(e0, f"wgrad {KH}x{KH}s{stride} {Cb}->{Ca} @{H}x{W} n{N}" + (f" x{len(chunk)}" if len(chunk) > 1 else ""),
+            _prof_end(e0, f"wgrad{'/wino' if algo else ''} {KH}x{KH}s{stride} {Cb}->{Ca} @{H}x{W} n{N}" + (f" x{len(chunk)}" if len(chunk) > 1 else ""),
                       2.0 * len(chunk) * N * Ca * Cb * KH * KW * OH * OW, side)
 
 

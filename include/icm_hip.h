@@ -142,6 +142,9 @@ typedef struct icm_wgrad_args {
   int64_t ws_floats;              /* capacity of ws in floats; 0 = unchecked. Too small -> ICM_ERR_ARG, nothing launched */
   int dw_ld;                      /* 0 = Cb; else the gradient lands in a [Ca][dw_ld][KH][KW] tensor whose b-columns
                                    * start at dw (an input-channel block of a wider weight); may differ per group member */
+  int algo;                       /* ICM_ALGO_DIRECT, or ICM_ALGO_WINOGRAD for 3x3 stride-1 pad-1 problems (fewer than
+                                   * 65 536 2x2 tiles): dU = (A dY A^T)(.)(B^T d B) summed over tiles, dW = G^T dU G;
+                                   * the workspace size depends on it (icm_wgrad_workspace_floats*) */
 } icm_wgrad_args;
 int64_t icm_wgrad_workspace_floats(const icm_wgrad_args* a);
 /* workspace PER PROBLEM when n problems of this geometry are issued by one icm_conv_wgrad_grouped call (the pixel

@@ -1046,3 +1046,47 @@ def test_winograd_grouped_lrp_residual_and_blocked_map(monkeypatch):
             close(res[True][k][i], res[False][k][i], tol=1e-5, what=f"wino vs direct {k}")
     close(res[True][5], F.conv2d(xs[0].cpu(), ws[0].cpu(), bs_[0].cpu(), padding=1), what="blocked map")
     close(res[True][5], res[False][5], tol=1e-5, what="blocked map wino vs direct")
+
+
+WINO_WG_CASES = [
+    # name, N, Cb (in), H, W, Ca (out), problems in the batch
+    ("ww_chain_224_176", 16, 224, 16, 16, 176, 3),
+    ("ww_first_320_224", 16, 320, 16, 16, 224, 2),
+    ("ww_ru_96_96", 2, 96, 64, 64, 96, 1),
+    ("ww_odd_40_72", 3, 40, 11, 13, 72, 2),
+    ("ww_small_24_200", 2, 24, 6, 10, 200, 1),
+]
+
+
+@pytest.mark.parametrize("case", WINO_WG_CASES, ids=[c[0] for c in WINO_WG_CASES])
+def test_winograd_wgrad_vs_torch_and_direct(case):
+    """csrc/wgrad_wino.hip (dU = (A dY A^T)(.)(B^T d B) over tiles, dW = G^T dU G in the reduction) through the
+    deferred / batched weight-gradient path: weight and fused bias gradients against torch.nn.grad.conv2d_weight on the
+    CPU and against the direct kernel; accumulation into an existing gradient; a column block of a wider weight (dw_ld)."""
+    from icm_amd import engine as E
+    _, N, Cb, H, Wd, Ca, nprob = case
+    d = dev()
+    res = {}
+    xs = [U(f"{case[0]}.x{i}", (N, Cb, H, Wd), -1.0, 1.0) for i in range(nprob)]
+    gs = [U(f"{case[0]}.g{i}", (N, Ca, H, Wd), -1.0, 1.0) for i in range(nprob)]
+    for algo in (1, 0):
+        tape = E.Tape(need_grad=True)
+        dws = [torch.full((Ca, Cb + 8, 3, 3), 0.5, device=d) for _ in range(nprob)]     # wider weight: columns [8, 8 + Cb)
+        dbs = [torch.zeros(Ca, device=d) for _ in range(nprob)]
+        keep = []
+        for i in range(nprob):
+            g_, x_ = gs[i].to(d), xs[i].to(d)
+            keep.append((g_, x_))
+            E.wgrad_defer(tape, g_, x_, dws[i][:, 8:], Ca=Ca, Cb=Cb, KH=3, KW=3, stride=1, pad=1, accum=1, dbias=dbs[i],
+                          accum_bias=0, dw_ld=Cb + 8, algo=algo)
+        E.flush_wgrads(tape)
+        torch.cuda.synchronize()
+        res[algo] = (dws, dbs)
+    for i in range(nprob):
+        ref = torch.nn.grad.conv2d_weight(xs[i], (Ca, Cb, 3, 3), gs[i], padding=1)
+        for algo in (1, 0):
+            dw = res[algo][0][i].cpu()
+            assert float((dw[:, :8] - 0.5).abs().max()) == 0.0, "columns outside the block were touched"
+            close(dw[:, 8:] - 0.5, ref, tol=5e-5, what=f"algo {algo} dW[{i}]")
+            close(res[algo][1][i], gs[i].sum(dim=(0, 2, 3)), tol=5e-5, what=f"algo {algo} dbias[{i}]")
+        close(res[1][0][i], res[0][0][i], tol=2e-5, what="wino vs direct")
