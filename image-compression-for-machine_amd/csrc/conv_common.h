@@ -265,6 +265,8 @@ int launch_conv_ks8(const ConvDesc& d, int tco, long long nblk, int ngroups, siz
 // Winograd F(2x2, 3x3) path (conv_wino.hip): 3x3 stride-1 pad-1 launches whose weights were packed with wino != 0
 bool wino_supported(const icm_conv_args& a);
 int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream);
+long long wino_transform_floats(const icm_conv_args& a);
+int run_wino_transform(const icm_conv_args* arr, int ngroups, hipStream_t stream);
 
 // pointwise path (conv_1x1.hip): ICM_OK after launching, -1 when the launch should take the LDS-staged kernel
 int run_conv1x1(const icm_conv_args* arr, int ngroups, long long wp_off, int force_mode, hipStream_t stream);

@@ -705,7 +705,7 @@ static int conv_run_grouped(const icm_conv_args* arr, int ngroups, hipStream_t s
         (b.res && b.res_bs != a.res_bs) || (b.aux && b.aux_bs != a.aux_bs) || (b.aux2 && b.aux2_bs != a.aux2_bs) ||
         (b.y2 && b.y2_bs != a.y2_bs) || (b.res != nullptr) != (a.res != nullptr) || (b.aux != nullptr) != (a.aux != nullptr) ||
         (b.aux2 != nullptr) != (a.aux2 != nullptr) || (b.y2 != nullptr) != (a.y2 != nullptr) ||
-        (b.bias != nullptr) != (a.bias != nullptr))
+        (b.bias != nullptr) != (a.bias != nullptr) || (b.xv != nullptr) != (a.xv != nullptr))
       return ICM_ERR_ARG;
   }
   if (a.algo == ICM_ALGO_WINOGRAD) return run_conv_wino(arr, ngroups, stream);
@@ -749,6 +749,18 @@ int icm_convT2d_fwd(const icm_conv_args* a, void* stream) {
 }
 
 int icm_conv_winograd_ok(const icm_conv_args* a) { return (a && icm::wino_supported(*a)) ? 1 : 0; }
+int64_t icm_wino_transform_floats(const icm_conv_args* a) {
+  return (a && icm::wino_supported(*a) && a->N > 0 && a->Cin > 0) ? (int64_t)icm::wino_transform_floats(*a) : -1;
+}
+int icm_wino_transform(const icm_conv_args* arr, int ngroups, void* stream) {
+  if (!arr || ngroups < 1 || ngroups > ICM_MAX_GROUPS) return ICM_ERR_ARG;
+  for (int i = 1; i < ngroups; ++i)
+    if (arr[i].N != arr[0].N || arr[i].Cin != arr[0].Cin || arr[i].H != arr[0].H || arr[i].W != arr[0].W ||
+        arr[i].x_bs != arr[0].x_bs || arr[i].pro_act != arr[0].pro_act || arr[i].x_seg_len != arr[0].x_seg_len ||
+        arr[i].x_seg_gap != arr[0].x_seg_gap)
+      return ICM_ERR_ARG;
+  return icm::run_wino_transform(arr, ngroups, (hipStream_t)stream);
+}
 
 void icm_debug_force_conv_cfg(int idx) { icm::g_force_cfg = idx; }
 int icm_debug_forced_conv_cfg(void) { return icm::g_force_cfg; }

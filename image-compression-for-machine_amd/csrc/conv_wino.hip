@@ -39,6 +39,7 @@ struct WinoDesc {
   FastDiv dseg;
   int dbg;            // measurement only (ICM_WINO_DEBUG): 1 = no patch loads, 2 = no weight loads in the loop, 4 = no stores,
                       // 8 = no input transform / LDS stores, 16 = no B-fragment LDS reads
+  int vpre;           // the operand pointer holds PRE-TRANSFORMED input (wino_input_transform_kernel): [px block][chunk][xi][ci][tile]
   int px_fast, npx;   // workgroup order: pixel blocks fastest (weights stationary per XCD) when the weights outweigh the activations
 };
 
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
   // its own 1/8 of the weights instead of all of them once per pixel block.
   const int cb = d.px_fast ? bid / d.npx : bid % d.ncb;
   int pt = d.px_fast ? bid % d.npx : bid / d.ncb;
+  const int pblk = pt;
   const int bx = pt % d.tiles_x;
   pt /= d.tiles_x;
   const int by = pt % d.tiles_y;
@@ -90,7 +92,32 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
   const int TXm = (1 << d.lgTX) - 1, TYm = (1 << d.lgTY) - 1;
   const int HW = d.H * d.W;
 
-  if (wave >= 4) {
+  if (wave >= 4 && d.vpre) {
+    // ------------------------------------------------------------------ loader waves, pre-transformed operand: LDS-DMA only.
+    // The transform ran once per input tensor in its own (HBM-bound, microsecond) launch instead of once per co-block
+    // here: no VALU / LDS-store work next to the MFMA waves (which cost them 15-25 %: f32 MFMA and VALU contend), and
+    // 16-byte coalesced DMA instead of 32 scattered dword gathers per lane and step.
+    const int lw = wave - 4;
+    const float* vsrc = P.x + (long long)pblk * (d.nsteps * 2) * 4096;
+    auto dma = [&](int step, int buf) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+          const int e = (rnd * 256 + lw * 64) * 4;   // float offset of this wave's 1 KB piece inside the 16 KB chunk
+          __builtin_amdgcn_global_load_lds(vsrc + ((long long)(step * 2 + k) * 4096 + e + lane * 4),
+                                           smem + buf * WINO_STEP_FLOATS + k * 4096 + e, 16, 0, 0);
+        }
+    };
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < d.nsteps; ++s) {
+      if (s + 1 < d.nsteps) dma(s + 1, (s + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // DMAs must have landed before the barrier publishes them
+      __syncthreads();
+    }
+  } else if (wave >= 4) {
     // ------------------------------------------------------------------ loader / input-transform waves
     const int q = (wave - 4) * 64 + lane;
     const int ci_l = q >> 5, t = q & 31;
@@ -286,6 +313,103 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
   }
 }
 
+bool wino_supported(const icm_conv_args& a);
+
+// ---- input transform as its own launch: V[px block][chunk][xi][ci][tile] = B^T d B of every 4x4 patch (zero padding, the
+// operand activation and the blocked channel map applied here).  One workgroup = one (px block, 8-channel chunk).
+struct WinoXfDesc {
+  const float* x[ICM_MAX_GROUPS];
+  float* v[ICM_MAX_GROUPS];
+  long long x_bs;
+  int N, Cin, H, W, lgTX, lgTY, lgTI, tiles_x, tiles_y, nchunks, act, seg_len, seg_gap;
+  FastDiv dseg;
+};
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(const WinoXfDesc d) {
+  const float* x = d.x[blockIdx.y];
+  float* v = d.v[blockIdx.y];
+  const int chunk = blockIdx.x % d.nchunks;
+  int pt = blockIdx.x / d.nchunks;
+  const int pblk = pt;
+  const int bx = pt % d.tiles_x;
+  pt /= d.tiles_x;
+  const int by = pt % d.tiles_y;
+  const int bn = pt / d.tiles_y;
+  const int q = threadIdx.x, ci_l = q >> 5, t = q & 31;
+  const int TXm = (1 << d.lgTX) - 1, TYm = (1 << d.lgTY) - 1;
+  const int tx = t & TXm, ty = (t >> d.lgTX) & TYm, ti = t >> (d.lgTX + d.lgTY);
+  const int n = (bn << d.lgTI) + ti;
+  const int oy = (((by << d.lgTY) + ty) << 1), ox = (((bx << d.lgTX) + tx) << 1);
+  const int c = chunk * 8 + ci_l;
+  const bool cok = c < d.Cin && n < d.N;
+  const int cp = d.seg_len ? c + (int)fdiv((uint32_t)c, d.dseg) * d.seg_gap : c;
+  const float* pc = x + ((long long)n * d.x_bs + (long long)cp * d.H * d.W + (long long)(oy - 1) * d.W + (ox - 1));
+  float dd[16], u[16];
+#pragma unroll
+  for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) {
+      const int iy = oy - 1 + dy, ix = ox - 1 + dx;
+      const float val = (cok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) ? pc[dy * d.W + dx] : 0.0f;
+      dd[dy * 4 + dx] = d.act ? apply_act(val, d.act) : val;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
+    u[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
+    u[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
+    u[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
+  }
+  float* dst = v + ((long long)pblk * d.nchunks + chunk) * 4096 + ci_l * 32 + t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    dst[(i * 4 + 0) * 256] = u[i * 4 + 0] - u[i * 4 + 2];
+    dst[(i * 4 + 1) * 256] = u[i * 4 + 1] + u[i * 4 + 2];
+    dst[(i * 4 + 2) * 256] = u[i * 4 + 2] - u[i * 4 + 1];
+    dst[(i * 4 + 3) * 256] = u[i * 4 + 1] - u[i * 4 + 3];
+  }
+}
+
+struct WinoGeom {
+  int lgTX, lgTY, lgTI, tiles_x, tiles_y, tiles_n, nchunks8, nsteps;
+};
+static WinoGeom wino_geometry(const icm_conv_args& a) {
+  WinoGeom g;
+  const int tw = cdiv(a.W, 2), th = cdiv(a.H, 2);   // tiles per image row / column
+  g.lgTX = std::min(3, ceil_log2(tw));
+  g.lgTY = std::min(5 - g.lgTX, ceil_log2(th));
+  g.lgTI = 5 - g.lgTX - g.lgTY;
+  g.tiles_x = cdiv(tw, 1 << g.lgTX); g.tiles_y = cdiv(th, 1 << g.lgTY); g.tiles_n = cdiv(a.N, 1 << g.lgTI);
+  g.nchunks8 = cdiv(a.Cin, 8); g.nsteps = cdiv(g.nchunks8, 2);
+  return g;
+}
+
+long long wino_transform_floats(const icm_conv_args& a) {
+  const WinoGeom g = wino_geometry(a);
+  return (long long)g.tiles_x * g.tiles_y * g.tiles_n * (g.nsteps * 2) * 4096;
+}
+
+int run_wino_transform(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
+  const icm_conv_args& a = arr[0];
+  if (!wino_supported(a)) return ICM_ERR_UNSUPPORTED;
+  const WinoGeom g = wino_geometry(a);
+  WinoXfDesc d{};
+  for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
+    const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
+    if (!s.x || !s.xv) return ICM_ERR_ARG;
+    d.x[gi] = s.x; d.v[gi] = s.xv;
+  }
+  d.x_bs = a.x_bs; d.N = a.N; d.Cin = a.Cin; d.H = a.H; d.W = a.W;
+  d.lgTX = g.lgTX; d.lgTY = g.lgTY; d.lgTI = g.lgTI; d.tiles_x = g.tiles_x; d.tiles_y = g.tiles_y;
+  d.nchunks = g.nsteps * 2; d.act = a.pro_act;
+  d.seg_len = a.x_seg_len; d.seg_gap = a.x_seg_len ? a.x_seg_gap : 0;
+  d.dseg = make_fastdiv((uint32_t)std::max(1, a.x_seg_len));
+  const long long nblk = (long long)g.tiles_x * g.tiles_y * g.tiles_n * d.nchunks;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)nblk, ngroups), dim3(256), 0, stream, d);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+
 bool wino_supported(const icm_conv_args& a) {
   if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.pixel_shuffle) return false;
   if (a.OH != a.H || a.OW != a.W) return false;
@@ -309,12 +433,19 @@ int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
   }
   d.x_bs = a.x_bs; d.y_bs = a.y_bs; d.res_bs = a.res_bs; d.aux_bs = a.aux_bs; d.y2_bs = a.y2_bs;
   d.N = a.N; d.Cin = a.Cin; d.Cout = a.Cout; d.H = a.H; d.W = a.W;
-  const int tw = cdiv(a.W, 2), th = cdiv(a.H, 2);   // tiles per image row / column
-  d.lgTX = std::min(3, ceil_log2(tw));
-  d.lgTY = std::min(5 - d.lgTX, ceil_log2(th));
-  d.lgTI = 5 - d.lgTX - d.lgTY;
-  d.tiles_x = cdiv(tw, 1 << d.lgTX); d.tiles_y = cdiv(th, 1 << d.lgTY); d.tiles_n = cdiv(a.N, 1 << d.lgTI);
-  d.ncot = cdiv(a.Cout, 32); d.nchunks8 = cdiv(a.Cin, 8); d.nsteps = cdiv(d.nchunks8, 2);
+  {
+    const WinoGeom g = wino_geometry(a);
+    d.lgTX = g.lgTX; d.lgTY = g.lgTY; d.lgTI = g.lgTI; d.tiles_x = g.tiles_x; d.tiles_y = g.tiles_y; d.tiles_n = g.tiles_n;
+    d.nchunks8 = g.nchunks8; d.nsteps = g.nsteps;
+  }
+  d.ncot = cdiv(a.Cout, 32);
+  d.vpre = a.xv != nullptr ? 1 : 0;
+  if (d.vpre)   // the operand of every member is its pre-transformed buffer
+    for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
+      const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
+      if (!s.xv) return ICM_ERR_ARG;
+      d.g[gi].x = s.xv;
+    }
   d.epi = a.epi; d.accum = a.accum; d.act = a.pro_act;
   d.seg_len = a.x_seg_len; d.seg_gap = a.x_seg_len ? a.x_seg_gap : 0;
   d.dseg = make_fastdiv((uint32_t)std::max(1, a.x_seg_len));

@@ -28,7 +28,7 @@ class ConvArgs(C.Structure):
         ("transposed", i32), ("pro_act", i32), ("epi", i32),
         ("res", vp), ("res_bs", i64), ("aux", vp), ("aux_bs", i64), ("aux2", vp), ("aux2_bs", i64),
         ("y2", vp), ("y2_bs", i64),
-        ("accum", i32), ("pixel_shuffle", i32), ("x_seg_len", i32), ("x_seg_gap", i32), ("algo", i32),
+        ("accum", i32), ("pixel_shuffle", i32), ("x_seg_len", i32), ("x_seg_gap", i32), ("algo", i32), ("xv", vp),
     ]
 
 
@@ -69,7 +69,7 @@ SYMBOLS = [
     "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_layernorm_fwd", "icm_layernorm_bwd", "icm_space_to_depth2",
-    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_gather_vectors", "icm_conv_winograd_ok", "icm_winattn_fwd", "icm_winattn_bwd",
+    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_gather_vectors", "icm_conv_winograd_ok", "icm_wino_transform_floats", "icm_wino_transform", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_adam_step_hyper", "icm_fill",
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_forced_conv_cfg", "icm_debug_force_conv1x1",
@@ -101,6 +101,9 @@ def lib():
         L.icm_pack_weights_batch.argtypes = [C.POINTER(PackJob), i32, vp]
         L.icm_conv_run.argtypes = [C.POINTER(ConvArgs), vp]
         L.icm_conv_winograd_ok.argtypes = [C.POINTER(ConvArgs)]
+        L.icm_wino_transform_floats.argtypes = [C.POINTER(ConvArgs)]
+        L.icm_wino_transform_floats.restype = i64
+        L.icm_wino_transform.argtypes = [C.POINTER(ConvArgs), i32, vp]
         L.icm_conv_run_grouped.argtypes = [C.POINTER(ConvArgs), i32, vp]
         for n in ("icm_conv2d_fwd", "icm_conv2d_dgrad", "icm_convT2d_fwd", "icm_convT2d_dgrad"):
             getattr(L, n).argtypes = [C.POINTER(ConvArgs), vp]

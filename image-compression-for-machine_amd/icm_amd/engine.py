@@ -28,10 +28,15 @@ _SKIP_WGRAD = _os.environ.get("ICM_DEBUG_SKIP_WGRAD", "0") == "1"
 PAIR_GATE_BRANCHES = _os.environ.get("ICM_PAIR_GATE_BRANCHES", "1") == "1"
 
 
+MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_common.h
+
+
 # Winograd F(2x2, 3x3) for the 3x3 stride-1 pad-1 convolutions (forward and input gradient; csrc/conv_wino.hip):
 # ICM_WINO=0 keeps the direct implicit-GEMM form everywhere (same-box A/B, and the reference point of the parity tests)
 USE_WINO = _os.environ.get("ICM_WINO", "1") != "0"
-_WINO_MIN_CIN = int(_os.environ.get("ICM_WINO_MIN_CIN", "16"))
+# contraction depth below which the direct kernels win even on large launches (ResidualUnit 3x3 96 -> 96 @64x64 x2:
+# 206 us direct, 255 us Winograd: six K steps do not amortise the transforms and the 16-point epilogue)
+_WINO_MIN_CIN = int(_os.environ.get("ICM_WINO_MIN_CIN", "128"))
 # Small launches are latency-bound (prologue gather + transform, LDS round trip of the output transform): below this
 # many multiply-adds of the DIRECT form per launch / 9 (N * H * W * Cin * Cout * members) the direct kernels win
 # (measured on MI355X, profiles/r03_wino_vs_direct.txt)
@@ -39,6 +44,12 @@ _WINO_MIN_WORK = float(_os.environ.get("ICM_WINO_MIN_WORK", "2.0e8"))
 # weight gradients are issued in batches of same-geometry problems (flush_wgrads): a single problem counts this many times
 _WINO_WG_BATCH = float(_os.environ.get("ICM_WINO_WG_BATCH", "4"))
 USE_WINO_WGRAD = _os.environ.get("ICM_WINO_WGRAD", "1") != "0"
+# input transform of the Winograd convolutions as its own launch (one per distinct input tensor of a launch) + LDS-DMA
+# staging in the convolution kernel, instead of gather + transform by the kernel's loader waves per co-block
+WINO_PRE = _os.environ.get("ICM_WINO_PRE", "1") != "0"
+# problems with many pixels keep the direct nine-tap single-staging kernel (96 -> 96 @64x64 x6: 716 us direct, 832 us
+# Winograd: its 96-wide blocks fit those layers exactly and K = 65 536 pixels amortises its staging)
+_WINO_WG_MAX_PIXELS = int(_os.environ.get("ICM_WINO_WG_MAX_PIXELS", "16384"))
 _WINO_EPIS = (EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_MUL_DGELU, EPI_RES_MUL_DGELU, EPI_LRP)
 
 
@@ -339,6 +350,26 @@ class Tape:
 
 
 # ------------------------------------------------------------------------------------------------ raw launches
+
+def _wino_pretransform(tape, arr, xs):
+    """fill arr[i].xv: B^T d B of every distinct input tensor of a Winograd launch, computed by ONE transform launch"""
+    lib = L.lib()
+    nfl = lib.icm_wino_transform_floats(C.byref(arr[0]))
+    if nfl <= 0:
+        raise ValueError("icm winograd transform: unsupported geometry")
+    bufs, firsts = {}, []
+    for i, x in enumerate(xs):
+        k = _key(x)
+        if k not in bufs:
+            bufs[k] = torch.empty(nfl, dtype=torch.float32, device=x.device)
+            firsts.append(i)
+        arr[i].xv = ptr(bufs[k])
+    for j0 in range(0, len(firsts), MAX_GROUP):
+        part = firsts[j0:j0 + MAX_GROUP]
+        tarr = (L.ConvArgs * len(part))(*[arr[i] for i in part])
+        check(lib.icm_wino_transform(tarr, len(part), tape.st), "wino_transform")
+    return bufs
+
 def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW, pro_act=ACT_NONE,
                 epi=EPI_NONE, res=None, aux=None, aux2=None, y2=None, accum=0, ps=0, tag="fwd", seg=None, algo=0):
     """seg = (run length, gap): blocked input-channel map (icm_conv_args.x_seg_len / x_seg_gap)"""
@@ -358,6 +389,11 @@ def conv_launch(tape, x, wp, bias, y, *, Cin, Cout, KH, KW, stride, pad, transpo
     if seg is not None:
         a.x_seg_len, a.x_seg_gap = seg
     a.algo = algo
+    keep = None
+    if algo and WINO_PRE:
+        arr1 = (L.ConvArgs * 1)(a)
+        keep = _wino_pretransform(tape, arr1, [x])
+        a = arr1[0]
     check(L.lib().icm_conv_run(C.byref(a), tape.st), "conv_run")
     if e0 is not None:
         px = H * W if transposed else OH * OW
@@ -395,8 +431,9 @@ def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE
     _, _, H, W = gb.shape
     if algo is None:   # Winograd form for 3x3 stride-1 problems (wgrad_wino.hip); the work of a batch is what counts, so the
         #                threshold is applied per problem with a typical batch factor folded into ICM_WINO_MIN_WORK_WG
-        algo = 1 if (USE_WINO_WGRAD and wino_ok(KH, KW, stride, pad, min(Ca, Cb), work=float(N) * OH * OW * Ca * Cb * _WINO_WG_BATCH)
-                     and N * ((OH + 1) // 2) * ((OW + 1) // 2) < 65536) else 0
+        algo = 1 if (USE_WINO_WGRAD and act_s == ACT_NONE and act_b == ACT_NONE and   # (materialised operands only)
+                     wino_ok(KH, KW, stride, pad, min(Ca, Cb), work=float(N) * OH * OW * Ca * Cb * _WINO_WG_BATCH)
+                     and N * OH * OW < _WINO_WG_MAX_PIXELS) else 0
     key = (Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, bs(gs), bs(gb), dbias is not None, algo)
     tape.wjobs.append((key, gs, gb, dw, accum, dbias, accum_bias, dw_ld))
 
@@ -671,6 +708,7 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
         if i and (bs(x) != bs(xs[0]) or bs(y) != bs(ys[0]) or bs(aux) != bs(auxs[0] if auxs else None)
                   or bs(y2) != bs(y2s[0] if y2s else None) or bs(res) != bs(ress[0] if ress else None)):
             raise ValueError("grouped conv: members must share strides")
+    keep = _wino_pretransform(tape, arr, xs) if (algo and WINO_PRE) else None
     check(L.lib().icm_conv_run_grouped(arr, n, tape.st), "conv_run_grouped")
     if e0 is not None:
         N, _, H, W = xs[0].shape
@@ -679,7 +717,6 @@ def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride,
                   2.0 * n * N * Cin * Cout * KH * KW * px)
 
 
-MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_igemm.hip
 
 
 def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, ress=None, pixel_shuffle=0,

@@ -167,12 +167,14 @@ def _copy_op(tape, src, dst):
         tape.bw.append(bwd)
 
 
-# ICM_SLICE_SPLIT=1 (default): the first layer of every slice chain is split by input-channel block (slices.py): the
-# latent block of all 3 * num_slices chains runs as two wide convolutions outside the serial slice loop.  0 = the
-# literal per-chain form below (cat -> chain), kept for same-box A/B measurements and as a second implementation the
-# parity tests compare against.
+# ICM_SLICE_SPLIT=1: the first layer of every slice chain is split by input-channel block (slices.py): the latent
+# block of all 3 * num_slices chains runs as two wide convolutions outside the serial slice loop.  0 (default) = the
+# per-chain form below (support buffers, cat -> chain).  Both are kept and both are parity-tested; the default is the
+# one that measured faster on MI355X in same-box A/B runs (round 3, with the Winograd kernels: 358.2 vs 354.9 img/s at
+# B=16; 348.0 vs 337.3 with the pre-transformed operands -- the split form's wide launches have few output tiles and
+# its support / own-slice blocks add ~30 small launches per direction).
 import os as _os
-SLICE_SPLIT = _os.environ.get("ICM_SLICE_SPLIT", "1") != "0"
+SLICE_SPLIT = _os.environ.get("ICM_SLICE_SPLIT", "0") != "0"
 
 
 def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, num_slices: int,

@@ -34,6 +34,11 @@ from . import engine as E
 from ._lib import ACT_GELU, EPI_NONE, check, ptr
 from .engine import VT, _key
 
+import os as _os
+# K-split factors of the wide input-gradient launches (0 / 1 = one launch): same-box A/B switches
+KSPLIT_A = int(_os.environ.get("ICM_KSPLIT_A", "4"))
+KSPLIT_B = _os.environ.get("ICM_KSPLIT_B", "1") != "0"
+
 FAM = ("cc_mean_transforms", "lrp_transforms", "cc_scale_transforms")   # PRE0 family order: the two latent_means consumers adjacent
 
 
@@ -46,6 +51,29 @@ def _tail_layers(tape, P, names, xvs, outs=None, lrp_auxs=None):
                             pad=1, outs=outs if last else None, lrp_auxs=lrp_auxs if last else None, act_out=not last)
         xvs = [VT(t, ACT_GELU) for t in ts]
     return ts
+
+
+def _ksplit_dgrad(tape, x, wp, K, Cout, taps, gx, acc, ks, conv_b, tag):
+    """Input gradient of a wide first-layer block, x [N, K, h, w] (contiguous channel range) -> gx [N, Cout, h, w], with
+    the contraction split into ``ks`` equal channel ranges that run as the members of ONE grouped launch and write
+    partial results, which are then added in member order (deterministic).  Such a launch has few output tiles (Cout =
+    160 / 320 channels x 4 096 pixels) and a very deep K: on its own it occupies 160 of the 256 CUs; split four ways
+    it fills whole rounds of the chip.  wp: the K-concatenated packed weights (chunk-major, so a channel range is a
+    pointer offset: taps * cdiv(Cout, 32) * 256 floats per 8 channels)."""
+    if ks <= 1 or K % (8 * ks):
+        E.conv_launch(tape, x, wp, None, gx, Cin=K, Cout=Cout, transposed=1, accum=acc, tag=tag, **conv_b)
+        return
+    kp = K // ks
+    per8 = taps * ((Cout + 31) // 32) * 256
+    N, _, h, w = x.shape
+    parts = [E.new((N, Cout, h, w), x.device) for _ in range(ks)]
+    E.conv_launch_grouped(tape, [x[:, i * kp:(i + 1) * kp] for i in range(ks)], [wp[(i * kp // 8) * per8:] for i in range(ks)],
+                          None, parts, Cin=kp, Cout=Cout, transposed=1, tag=tag, **conv_b)
+    for i, part in enumerate(parts):
+        if gx.is_contiguous():
+            check(L.lib().icm_add_grad(ptr(part), 0, ptr(gx), part.numel(), acc if i == 0 else 1, tape.st), "add_grad")
+        else:
+            E.copy_into(tape, part, gx, acc if i == 0 else 1)
 
 
 def _block_grad(tape, w):
@@ -180,8 +208,8 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
                 _, wbk, conv_b = algo(len(mem) * D0, M)
                 wpb = tape.pack_cat([(W0[k_], 0) for k_ in mem], M, D0, KH, KH, 0, 1, 1, pad, "K", wino=wbk)
                 gx, acc = tape.grad_for_write(xin)
-                E.conv_launch(tape, DPRE0[:, c0:c0 + len(mem) * D0], wpb, None, gx, Cin=len(mem) * D0, Cout=M,
-                              transposed=1, accum=acc, tag="dgrad(A)", **conv_b)
+                _ksplit_dgrad(tape, DPRE0[:, c0:c0 + len(mem) * D0], wpb, len(mem) * D0, M, 16 if wbk else KH * KH, gx, acc,
+                              KSPLIT_A, conv_b, "dgrad(A)")
         tape.bw.append(bwd_A)
 
     # ---------------------------------------------------------------------------------------------- B / C helpers
@@ -212,8 +240,19 @@ def hyper_slices_split(tape: E.Tape, P: Dict[str, torch.Tensor], y, noise_z, noi
                 wpb = tape.pack_cat([(W0[(i, f)], M) for f in range(3) for i in idx], c * k, D0, KH, KH, 0, 1, 1, pad, "K",
                                     wino=wbk)
                 gx, acc = tape.grad_for_write(sup)
-                E.conv_launch(tape, DPRE0[:, r0[0]:], wpb, None, gx, Cin=3 * n * D0, Cout=c * k, transposed=1, accum=acc,
-                              seg=(n * D0, (S - n) * D0), tag="dgrad(B)", **conv_b)
+                if n > 1 and KSPLIT_B:
+                    # batch of tail slices: one member per family (each a contiguous channel run: no blocked map needed),
+                    # partial sums added in family order
+                    per8 = (16 if wbk else KH * KH) * ((c * k + 31) // 32) * 256
+                    parts = [E.new((N, c * k, h, w), dev) for _ in range(3)]
+                    E.conv_launch_grouped(tape, [DPRE0[:, r:r + n * D0] for r in r0],
+                                          [wpb[(f * n * D0 // 8) * per8:] for f in range(3)], None, parts, Cin=n * D0,
+                                          Cout=c * k, transposed=1, tag="dgrad(B)", **conv_b)
+                    for f, part in enumerate(parts):
+                        E.copy_into(tape, part, gx, acc if f == 0 else 1)
+                else:
+                    E.conv_launch(tape, DPRE0[:, r0[0]:], wpb, None, gx, Cin=3 * n * D0, Cout=c * k, transposed=1,
+                                  accum=acc, seg=(n * D0, (S - n) * D0), tag="dgrad(B)", **conv_b)
             tape.bind_grad(sup, dYh[:, :c * k], True)
             tape.bw.append(bwd_B)
 

@@ -83,11 +83,20 @@ typedef struct icm_conv_args {
    * (icm_pack_job.wino: 1 for the forward orientation, 2 for the input-gradient orientation).  Same f32 arithmetic
    * type, 4/9 of the multiply-adds; results agree with the direct form to summation-order noise. */
   int algo;
+  /* ICM_ALGO_WINOGRAD only, optional: the input pre-transformed by icm_wino_transform (icm_wino_transform_floats
+   * floats, caller-owned).  When set, icm_conv_run reads xv instead of x (operand activation and channel map were
+   * applied by the transform): one transform per input tensor serves every launch and co-block that reads it, and
+   * the convolution kernel stages its operand by 16-byte LDS-DMA with no vector work next to the matrix pipe. */
+  float* xv;
 } icm_conv_args;
 #define ICM_ALGO_DIRECT 0
 #define ICM_ALGO_WINOGRAD 1
 /* 1 if icm_conv_run accepts these arguments with algo = ICM_ALGO_WINOGRAD (geometry and epilogue kind supported) */
 int icm_conv_winograd_ok(const icm_conv_args* a);
+/* size of the pre-transformed operand of these arguments (-1 if unsupported), and the transform itself: fills
+ * arr[i].xv from arr[i].x for up to 12 same-geometry members in one launch */
+int64_t icm_wino_transform_floats(const icm_conv_args* a);
+int icm_wino_transform(const icm_conv_args* arr, int ngroups, void* stream);
 
 int icm_conv_run(const icm_conv_args* a, void* stream);
 /* up to 3 problems of identical geometry in one launch (cc_mean || cc_scale chains, cnn.py:164-168) */

@@ -77,8 +77,13 @@ def test_b16_eval_forward_vs_oracle():
         assert e < 5e-6, k   # measured 1.2e-7 (north_star bound: 1e-4 relative)
 
 
-def test_b16_trainer_steps_vs_oracle():
-    """the bench's own first two steps (noise=None: drawn from the trainer's generator) against the oracle loop"""
+@pytest.mark.parametrize("slice_split", [False, True], ids=["default", "split_slices"])
+def test_b16_trainer_steps_vs_oracle(slice_split, monkeypatch):
+    """the bench's own first two steps (noise=None: drawn from the trainer's generator) against the oracle loop; once
+    more with the slice section in its split form (icm_amd/slices.py: wide latent-block launches, K-split input
+    gradients, column-block weight gradients -- paths that only exist at this geometry)"""
+    from icm_amd import models as M_
+    monkeypatch.setattr(M_, "SLICE_SPLIT", slice_split)
     from icm_amd.models import wacnn_forward
     bench = _bench()
     dev = torch.device(DEV)

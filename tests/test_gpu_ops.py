@@ -977,10 +977,12 @@ def test_winograd_conv_vs_torch_and_direct(case, monkeypatch):
     yr.backward(g)
     outs = {}
     monkeypatch.setattr(E, "_MAT_MIN_PIXELS", 0)
-    monkeypatch.setattr(E, "_WINO_MIN_WORK", 0.0)     # (by default small launches stay on the direct kernels)
+    monkeypatch.setattr(E, "_WINO_MIN_WORK", 0.0)     # (by default small / shallow launches stay on the direct kernels)
+    monkeypatch.setattr(E, "_WINO_MIN_CIN", 16)
     for name, on in (("wino", True), ("direct", False)):
         monkeypatch.setattr(E, "USE_WINO", on)
         assert E.wino_ok(3, 3, 1, 1, Cin) == on
+        monkeypatch.setattr(E, "WINO_PRE", N % 2 == 0)    # both placements of the input transform across the cases
         tape = E.Tape(need_grad=True)
         xd = x.to(d)
         wd_, bd = w.to(d), b.to(d)

@@ -150,21 +150,25 @@ def test_train_step_grads_vs_reference_fixture(golden_dir, model):
         assert r < (2e-4 if flips == 0 else 5e-2), n   # one flipped latent moves x_hat-dependent gradients by ~1e-2
 
 
-@pytest.mark.parametrize("variant", ["default", "winograd_everywhere", "no_winograd", "unsplit_slices"])
+@pytest.mark.parametrize("variant", ["default", "winograd_everywhere", "no_winograd", "split_slices",
+                                     "split_slices_winograd_everywhere", "winograd_in_kernel_transform"])
 def test_train_grads_vs_oracle_small(variant, monkeypatch):
     """64x64 input, oracle autograd as reference: EVERY parameter gradient, unconditionally -- the oracle adopts the HIP
     path's rounding decisions (flips are counted and bounded separately)"""
-    # the same check under every implementation variant of the 3x3 convolutions / slice section: the Winograd kernel
-    # forced onto every eligible launch (by default small launches stay on the direct kernels), no Winograd at all, and
-    # the literal per-chain slice loop (first layers not split)
+    # the same check under every implementation variant of the 3x3 convolutions / slice section: the Winograd kernels
+    # forced onto every eligible launch (by default small launches stay on the direct kernels), with the input
+    # transform inside the kernel instead of its own launch, no Winograd at all, and the slice loop with its first
+    # layers split by input-channel block (icm_amd/slices.py)
     from icm_amd import engine as E_
     from icm_amd import models as M_
-    if variant == "winograd_everywhere":
+    if "winograd_everywhere" in variant or variant == "winograd_in_kernel_transform":
         monkeypatch.setattr(E_, "_WINO_MIN_WORK", 0.0)
-    elif variant == "no_winograd":
+        monkeypatch.setattr(E_, "_WINO_MIN_CIN", 16)
+    if variant == "winograd_in_kernel_transform":
+        monkeypatch.setattr(E_, "WINO_PRE", False)
+    if variant == "no_winograd":
         monkeypatch.setattr(E_, "USE_WINO", False)
-    elif variant == "unsplit_slices":
-        monkeypatch.setattr(M_, "SLICE_SPLIT", False)
+    monkeypatch.setattr(M_, "SLICE_SPLIT", variant.startswith("split_slices"))
     from icm_amd.zoo import models
     from icm_amd.losses import RateDistortionLoss
     from icm_amd.layers import _named

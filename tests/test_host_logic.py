@@ -104,9 +104,12 @@ def dry(monkeypatch):
     return fake
 
 
-def test_wacnn_tape_plumbing_dry_run(dry):
+@pytest.mark.parametrize("slice_split", [False, True], ids=["default", "split_slices"])
+def test_wacnn_tape_plumbing_dry_run(dry, slice_split, monkeypatch):
     from icm_amd.zoo import models
     from icm_amd.losses import RateDistortionLoss
+    from icm_amd import models as M_
+    monkeypatch.setattr(M_, "SLICE_SPLIT", slice_split)
     torch.manual_seed(0)
     net = models["cnn"]().train()
     x = torch.rand(2, 3, 64, 64)
@@ -121,13 +124,20 @@ def test_wacnn_tape_plumbing_dry_run(dry):
     for n, p in net.named_parameters():
         if p.grad is not None:
             assert p.grad.shape == p.shape, n
-    # grouped launches of the slice section (icm_amd/slices.py), forward: slice 0's latent blocks (1), 4 support blocks
-    # and 5 own-slice blocks of the serial slices, their second..fifth layers (5 x (4 + 4)), and for the batch of tail
-    # slices 5..9 one support block, one own-slice block and 4 + 4 layers; backward: the same second..fifth layers and the
-    # own-slice blocks (the support / latent input gradients are single wide launches).  Plus the 4 gates (3
-    # ResidualUnit steps x 3 convs of the two branches paired) and the h_scale_s / h_mean_s pair, forward and backward.
-    assert dry.calls["icm_conv_run_grouped"] == (1 + 4 + 5 + 40 + 10) + (40 + 8 + 6) + 2 * (4 * 9 + 5)
-    assert dry.calls["icm_conv_run"] >= 60 and dry.calls["icm_gather_vectors"] == 1
+    if slice_split:
+        # grouped launches of the slice section (icm_amd/slices.py), forward: slice 0's latent blocks (1), 4 support blocks
+        # and 5 own-slice blocks of the serial slices, their second..fifth layers (5 x (4 + 4)), and for the batch of tail
+        # slices 5..9 one support block, one own-slice block and 4 + 4 layers; backward: the same second..fifth layers, the
+        # own-slice blocks and 3 K-split wide input gradients (the serial slices' support input gradients are single
+        # launches).  Plus the 4 gates (3 ResidualUnit steps x 3 convs of the two branches paired) and the h_scale_s /
+        # h_mean_s pair, forward and backward.
+        assert dry.calls["icm_conv_run_grouped"] == (1 + 4 + 5 + 40 + 10) + (40 + 8 + 6) + 3 + 2 * (4 * 9 + 5)
+        assert dry.calls["icm_conv_run"] >= 60 and dry.calls["icm_gather_vectors"] == 1
+    else:
+        # grouped launches (forward and dgrad): the mean/scale pair of the 5 serial slices (5 x 5 convs), then the 10
+        # mean/scale chains and the 5 lrp chains of the independent tail slices 5..9 as one chain each (5 + 5 layers);
+        # plus the 4 gates and the h_scale_s / h_mean_s pair
+        assert dry.calls["icm_conv_run"] > 100 and dry.calls["icm_conv_run_grouped"] == 2 * (25 + 5 + 5 + 4 * 9 + 5)
     assert 20 <= dry.calls["icm_conv_wgrad_grouped"] <= 80 and dry.calls.get("icm_conv_wgrad", 0) == 6
     assert dry.calls["icm_gc_likelihood_ste_fwd"] == 10 and dry.calls["icm_gc_likelihood_ste_bwd"] == 10
     assert dry.calls["icm_winattn_fwd"] == 4 and dry.calls["icm_winattn_bwd"] == 4
