@@ -58,12 +58,12 @@ def make_workload(model_name, dev, rank=0, group=None, batch=BATCH_PER_GPU):
 
 def family_of(label):
     if label.startswith("wgrad"):
-        return "wgrad_* kernels + wgrad_reduce_kernel (weight gradients)"
+        return "wgrad_* kernels (direct + wgrad_wino_kernel) + wgrad_reduce_kernel (weight gradients)"
     if label.startswith("winattn"):
         return "winattn kernels (window attention core)"
     if label.startswith("pack"):
         return "pack_weights kernels"
-    return "conv_igemm_kernel + conv1x1_kernel + conv_ks8_kernel (forward + input gradients)"
+    return "conv_igemm_kernel + conv1x1_kernel + conv_ks8_kernel + conv_wino_kernel (forward + input gradients)"
 
 
 def shape_table(run_step, top=24):
@@ -110,7 +110,7 @@ def pmc_traffic(kind):
     """HBM bytes per launch of the family's heaviest launch from the committed rocprofv3 PMC passes of this round
     (separate FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_family.sh)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_family.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_family.json")) as fh:
             return json.load(fh).get(kind)
     except Exception:
         return None
@@ -313,7 +313,7 @@ def main():
                 "avg_launch_ms": f["ms"] / max(1, f["launches"]),
                 "note": "family aggregate over one serialised step: sum of algorithmic FLOP of its launches / sum of "
                         "their HIP-event durations on the launch stream; traffic = HBM bytes of the family's heaviest "
-                        "launch from the committed PMC passes (profiles/r02_pmc_family.json), null if absent"}
+                        "launch from the committed PMC passes (profiles/r03_pmc_family.json), null if absent"}
             line["roofline_families"] = fams
             line["roofline_shapes"] = rows
             line["profiled_step"] = {"kernel_ms_sum": round(ktot, 3), "wall_ms": round(wall, 3)}

@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvDesc d) {
   int zero[TPX];
 #pragma unroll
   for (int tp = 0; tp < TPX; ++tp) zero[tp] = 0;
-  epilogue_dispatch<TCO, TPX, true>(d, P, acc, cot0, h, pn, zero, phw, pv);
+  // the pipelined two-operand epilogue holds two sets of operand registers: with 6 accumulator tiles (TCO 3 x TPX 2)
+  // it spilled 40 VGPRs (164 B scratch per lane); that instantiation takes the batched half-tile form
+  epilogue_dispatch<TCO, TPX, !(TCO == 3 && TPX == 2)>(d, P, acc, cot0, h, pn, zero, phw, pv);
 }
 
 struct Cfg1x1 {

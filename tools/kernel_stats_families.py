@@ -10,8 +10,8 @@ for r in rows:
     n, t, c = r["Name"], float(r["TotalDurationNs"]) / 1e6, int(r["Calls"])
     if "wgrad" in n:
         k = "wgrad_* kernels + wgrad_reduce_kernel"
-    elif "conv_igemm" in n or "conv1x1" in n or "conv_ks8" in n:
-        k = "conv_igemm_kernel + conv1x1_kernel + conv_ks8_kernel"
+    elif "conv_igemm" in n or "conv1x1" in n or "conv_ks8" in n or "conv_wino" in n or "wino_input_transform" in n:
+        k = "conv_igemm_kernel + conv1x1_kernel + conv_ks8_kernel + conv_wino_kernel (+ wino_input_transform)"
     elif "winattn" in n:
         k = "winattn kernels"
     elif "pack_weights" in n:

@@ -1,9 +1,9 @@
-"""Summarise tools/pmc_family.sh (gpurun_out/pmcf_*) into profiles/r02_pmc_family.json.
+"""Summarise tools/pmc_family.sh (gpurun_out/pmcf_*) into profiles/r03_pmc_family.json.
 HBM-side bytes per launch = FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, both in KB
 in the counter output; separate passes per counter set; averages over the launches of the named kernel."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_pmc_family.json")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_pmc_family.json")
 WHAT = {
     "wg5": ("wgrad", "wgrad_", "wgrad 5x5 s2 192->192 on [16,192,128,128] (g_a.2 / g_s.6)",
             4 * (16 * 192 * 128 * 128 + 16 * 192 * 64 * 64 + 192 * 192 * 25), 2.0 * 16 * 192 * 192 * 25 * 64 * 64),
@@ -11,6 +11,12 @@ WHAT = {
             4 * (2 * 16 * 192 * 64 * 64 + 192 * 192), 2.0 * 16 * 192 * 192 * 64 * 64),
     "conv": ("conv", "conv_igemm_kernel", "g_a.2 forward conv5x5 s2 192->192 on [16,192,128,128]",
              4 * (16 * 192 * 128 * 128 + 16 * 192 * 64 * 64 + 192 * 192 * 25), 2.0 * 16 * 192 * 192 * 25 * 64 * 64),
+    # Winograd kernels (round 3): algorithmic bytes / FLOP of the DIRECT form of the same problem (what the launch
+    # computes); the kernel executes 4/9 of the multiply-adds and moves the 16-point weights / transformed operands
+    "wino": ("conv_wino", "conv_wino_kernel", "slice-chain second layer conv3x3 224->176 on [16,224,16,16] x 10 members (Winograd F(2x2,3x3))",
+             10 * 4 * (16 * 224 * 256 + 16 * 176 * 256 + 176 * 224 * 9), 2.0 * 9 * 10 * 16 * 256 * 224 * 176),
+    "wwino": ("wgrad_wino", "wgrad_wino_kernel", "slice-chain first-layer wgrad 3x3 512->224 on [16,512,16,16] x 5 problems (Winograd)",
+              5 * 4 * (16 * 512 * 256 + 16 * 224 * 256 + 224 * 512 * 9), 2.0 * 9 * 5 * 16 * 256 * 512 * 224),
 }
 res = {}
 for tag, (key, kmatch, workload, alg, flop) in WHAT.items():
