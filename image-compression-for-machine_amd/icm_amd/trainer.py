@@ -111,7 +111,9 @@ class GradReducer:
         self.works = []
         self.launched = 0     # collectives issued (tests)
 
-    def launch(self, bucket: int):
+    def launch(self, bucket: int, after=()):
+        """all-reduce bucket `bucket`; after: extra events (recorded on other streams, e.g. the weight-gradient side
+        stream) the collective must wait for besides everything issued so far on the current stream"""
         if not self.active:
             return
         a, b = self.ranges[bucket]
@@ -121,6 +123,8 @@ class GradReducer:
         self.launched += 1
         if self.cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal path (several ranks sharing one GPU): stage through the host
+            for e in after:
+                e.synchronize()
             torch.cuda.current_stream().synchronize()
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -131,6 +135,8 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                for e in after:
+                    self.stream.wait_event(e)
                 self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -349,9 +355,17 @@ class Trainer:
         def mark(b):
             if b == 1:
                 tape.hold_wgrads = False
-            E.flush_wgrads(tape)
-            tape.join_side()
-            self.reducer.launch(b)
+            if self.reducer.active:
+                # the bucket is complete once the weight gradients queued so far have run on the side stream: the
+                # COLLECTIVE waits for them (event on the side stream); the main stream's input-gradient chain does not
+                # (round 2 joined the streams here, stalling backward at every bucket boundary)
+                E.flush_wgrads(tape)
+                after = ()
+                if tape.side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(tape.side)
+                    after = (ev,)
+                self.reducer.launch(b, after)
             if b == 0 and self.hold_chain_wgrads:
                 tape.hold_wgrads = True
         for name, idx in sorted(marks.items(), key=lambda kv: -kv[1]):
@@ -360,7 +374,7 @@ class Trainer:
         self._side_ws = tape._side_ws
         if tape.pack_log is not None and self._pack_seq is None:
             self._pack_seq = tape.pack_log
-        self.reducer.launch(len(BUCKETS) - 1)   # g_a: last gradients to complete
+        self.reducer.launch(len(BUCKETS) - 1)   # g_a: last gradients to complete (tape.backward() joined the side stream)
         if len(f.bucket_ranges) > len(BUCKETS):
             self.reducer.launch(len(BUCKETS))
         self.reducer.finish()

@@ -44,7 +44,7 @@ def main():
         p_init = tr.flat.p.clone().cpu()
         fired = []
         launch = tr.reducer.launch
-        tr.reducer.launch = lambda b: (fired.append(b), launch(b))[1]
+        tr.reducer.launch = lambda b, after=(): (fired.append(b), launch(b, after))[1]
         x, noises = inputs()
         scal = []
         for it in range(2):

@@ -115,12 +115,12 @@ def _step_worker(rank, world, port, q):
         fired = []
         launch = tr.reducer.launch
 
-        def spy(b):
+        def spy(b, after=()):
             # stand-in for the kernels: this rank's gradient of bucket b is (rank + 1) everywhere
             a, e = tr.flat.bucket_ranges[b]
             tr.flat.g[a:e] = float(rank + 1)
             fired.append(b)
-            launch(b)
+            launch(b, after)
         tr.reducer.launch = spy
         n1 = torch.rand(1, generator=tr.gen)
         tr.step(torch.rand(2, 3, 64, 64))
