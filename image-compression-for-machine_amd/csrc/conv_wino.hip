@@ -313,6 +313,176 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const WinoDesc d) {
   }
 }
 
+
+// ---- eight MFMA waves on pre-transformed operands (the default path): no loader waves at all.
+// With the input transform in its own launch the loaders only issue LDS-DMA, and what bounds the 4 + 4 kernel above is the
+// transformed operand itself: 32 KB of V per step feed just 2 co tiles (rocprofv3: matrix pipe 42 % busy, waves parked
+// 65 % of their cycles, 5.6x the algorithmic bytes from L2 / fabric).  Here all eight waves multiply -- wave w owns
+// transform row w >> 1, columns 2 (w & 1) and 2 (w & 1) + 1 -- so the same 128 accumulator registers hold TCO = 4 co
+// tiles: every staged V byte feeds twice the MFMAs, a step is twice as long (half the barriers), two MFMA waves per
+// SIMD cover each other's waits, and each wave issues 4 of the step's 32 DMA instructions itself.  The column half of
+// the output transform is split between the two waves of a row (partial sums through LDS, fixed order).
+template <int TCO>
+__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(const WinoDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ConvPtrs P = d.g[blockIdx.y];
+  int bid;
+  {
+    const int nb = gridDim.x, hb = blockIdx.x;
+    const int xcd = hb & 7, q = hb >> 3;
+    bid = xcd * (nb >> 3) + min(xcd, nb & 7) + q;
+  }
+  const int cb = d.px_fast ? bid / d.npx : bid % d.ncb;
+  int pt = d.px_fast ? bid % d.npx : bid / d.ncb;
+  const int pblk = pt;
+  const int bx = pt % d.tiles_x;
+  pt /= d.tiles_x;
+  const int by = pt % d.tiles_y;
+  const int bn = pt / d.tiles_y;
+  const int TXm = (1 << d.lgTX) - 1, TYm = (1 << d.lgTY) - 1;
+  const int HW = d.H * d.W;
+  const int r = wave >> 1, ch = wave & 1;
+  const int cot0 = cb * TCO;
+
+  const float* vsrc = P.x + (long long)pblk * (d.nsteps * 2) * 4096;
+  auto dma = [&](int step, int buf) {   // this wave's 4 of the 32 one-KB pieces of the step
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave + 8 * i;                 // 0..31: chunk piece >> 4, 1 KB piece & 15 inside the 16 KB chunk
+      const int e = (piece >> 4) * 4096 + (piece & 15) * 256;
+      __builtin_amdgcn_global_load_lds(vsrc + (long long)step * 8192 + e + lane * 4, smem + buf * WINO_STEP_FLOATS + e, 16, 0, 0);
+    }
+  };
+  f32x16 acc[2][TCO];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[c][a][e] = 0.0f;
+  const char* wbase = reinterpret_cast<const char*>(P.wp);
+  unsigned wl[TCO];
+#pragma unroll
+  for (int a = 0; a < TCO; ++a) wl[a] = (unsigned)(min(cot0 + a, d.ncot - 1) * 64 + lane) * 16u;
+  const long long qstride = (long long)d.ncot * 64 * 16;
+  const int nunits = d.nsteps * 4;                         // (chunk, column) units of this wave: two chunks x two columns per step
+  const int lastq = d.nchunks8 * 16 - 1;
+  const int xi0 = 4 * r + 2 * ch;
+  auto wptr = [&](int g) -> const char* {                  // unit g = chunk * 2 + column
+    const int qq = min((g >> 1) * 16 + xi0 + (g & 1), lastq);
+    return wbase + qq * qstride;
+  };
+  dma(0, 0);
+  f32x4 aq[4][TCO];
+#pragma unroll
+  for (int u = 0; u < 3; ++u)
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) aq[u][a] = *reinterpret_cast<const f32x4*>(wptr(min(u, nunits - 1)) + wl[a]);
+  const int boff = xi0 * 256 + lane;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // step 0 landed
+  for (int s = 0; s < d.nsteps; ++s) {
+    if (s + 1 < d.nsteps) dma(s + 1, (s + 1) & 1);   // issued first: older than every weight load of this step
+    const float* vb = smem + (s & 1) * WINO_STEP_FLOATS + boff;
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[0][j] = vb[j * 64];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = s * 4 + u;
+      if (u + 1 < 4) {
+        const float* nb = vb + ((u + 1) >> 1) * (16 * 256) + ((u + 1) & 1) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[(u + 1) & 1][j] = nb[j * 64];
+      }
+      const char* sp = wptr(min(g + 3, nunits - 1));
+#pragma unroll
+      for (int a = 0; a < TCO; ++a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[u & 1][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][a][j], bv[u & 1][j], acc[u & 1][a], 0, 0, 0);
+        aq[(u + 3) & 3][a] = *reinterpret_cast<const f32x4*>(sp + wl[a]);
+      }
+    }
+    // the DMAs of the next step are older than the 3 * TCO weight loads still in flight: wait for them only
+    if constexpr (TCO == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (TCO == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads of the buffer are complete
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- output transform.  Column half per wave pair of a row: ch 0 holds M0, M1; ch 1 holds M2, M3
+  //      Z[.][0] = (M0 + M1) + M2,   Z[.][1] = M1 + (-M2 - M3):  each wave contributes one partial per Z
+  float* zb = smem;   // per pass of two co tiles: [a 2][row 4][ch 2][cp 2][e 16][lane 64] = 128 KB
+  const int h = lane >> 5, l31 = lane & 31;
+  const int tx = l31 & TXm, ty = (l31 >> d.lgTX) & TYm, ti = l31 >> (d.lgTX + d.lgTY);
+  const int n = (bn << d.lgTI) + ti;
+  const int oy = (((by << d.lgTY) + ty) << 1), ox = (((bx << d.lgTX) + tx) << 1);
+  const bool nok = n < d.N;
+  P.y += (long long)n * d.y_bs;
+  if (P.y2) P.y2 += (long long)n * d.y2_bs;
+  if (P.res) P.res += (long long)n * d.res_bs;
+  if (P.aux) P.aux += (long long)n * d.aux_bs;
+#pragma unroll
+  for (int a0 = 0; a0 < TCO; a0 += 2) {
+    __syncthreads();   // staging buffers / the previous pass are free
+#pragma unroll
+    for (int al = 0; al < 2; ++al) {
+      if (a0 + al >= TCO) break;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float m0 = acc[0][a0 + al][e], m1 = acc[1][a0 + al][e];
+        const float p0 = ch == 0 ? m0 + m1 : m0;
+        const float p1 = ch == 0 ? m1 : -m0 - m1;
+        zb[((((al * 4 + r) * 2 + ch) * 2 + 0) * 16 + e) * 64 + lane] = p0;
+        zb[((((al * 4 + r) * 2 + ch) * 2 + 1) * 16 + e) * 64 + lane] = p1;
+      }
+    }
+    __syncthreads();
+    auto finish_all = [&](auto epi_tag) {
+      constexpr int EPI = decltype(epi_tag)::value;
+#pragma unroll
+      for (int al = 0; al < 2; ++al) {
+        const int cot = cot0 + a0 + al;
+        if (a0 + al >= TCO || cot >= d.ncot) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int e = wave + 8 * i;
+          const int co = cot * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          float z[4][2];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp)
+              z[rr][cp] = zb[((((al * 4 + rr) * 2 + 0) * 2 + cp) * 16 + e) * 64 + lane] +
+                          zb[((((al * 4 + rr) * 2 + 1) * 2 + cp) * 16 + e) * 64 + lane];
+          const bool cok = nok && co < d.Cout;
+          const long long base = (long long)co * HW + (long long)oy * d.W + ox;
+#pragma unroll
+          for (int cp = 0; cp < 2; ++cp) {
+            const float y0 = (z[0][cp] + z[1][cp]) + z[2][cp];
+            const float y1 = (z[1][cp] - z[2][cp]) - z[3][cp];
+            const bool xok = cok && ox + cp < d.W;
+            wino_finish<EPI>(d, P, y0, co, base + cp, xok && oy < d.H);
+            wino_finish<EPI>(d, P, y1, co, base + d.W + cp, xok && oy + 1 < d.H);
+          }
+        }
+      }
+    };
+    switch (d.epi) {
+      case ICM_EPI_RES: finish_all(std::integral_constant<int, ICM_EPI_RES>{}); break;
+      case ICM_EPI_RES_GELU: finish_all(std::integral_constant<int, ICM_EPI_RES_GELU>{}); break;
+      case ICM_EPI_MUL_DGELU: finish_all(std::integral_constant<int, ICM_EPI_MUL_DGELU>{}); break;
+      case ICM_EPI_RES_MUL_DGELU: finish_all(std::integral_constant<int, ICM_EPI_RES_MUL_DGELU>{}); break;
+      case ICM_EPI_LRP: finish_all(std::integral_constant<int, ICM_EPI_LRP>{}); break;
+      default: finish_all(std::integral_constant<int, ICM_EPI_NONE>{}); break;
+    }
+  }
+}
+
 bool wino_supported(const icm_conv_args& a);
 
 // ---- input transform as its own launch: V[px block][chunk][xi][ci][tile] = B^T d B of every 4x4 patch (zero padding, the
@@ -460,6 +630,24 @@ int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
     if (force_tco == 1 || force_tco == 2) tco = force_tco;
     (void)b1;
   }
+  // pre-transformed operand: the eight-MFMA-wave kernel, TCO in {2, 3, 4}: whole rounds of the chip, then wide co blocks
+  static const int w8_on = getenv("ICM_WINO8") ? atoi(getenv("ICM_WINO8")) : 1;
+  bool w8 = d.vpre && w8_on;
+  if (w8) {
+    int t8 = 2;
+    double bestc = 1e300;
+    for (int t = 4; t >= 2; --t) {
+      const long long b = pblocks * cdiv(d.ncot, t) * ngroups;
+      const double c = std::ceil(b / 256.0) * (t + 0.6);
+      if (c < bestc - 1e-9) { bestc = c; t8 = t; }
+    }
+    if (force_tco >= 2 && force_tco <= 4) t8 = force_tco;
+    // launches that cannot give the wide workgroups a (nearly) full round of the chip keep the 4 + 4 kernel with its
+    // narrower co blocks (measured: 224 -> 176 single 46.6 vs 54.4 us, 176 -> 128 x2 41.9 vs 49.9 us, 3360 -> 160 607 vs 746 us)
+    static const long long w8_min = getenv("ICM_WINO8_MINWG") ? atoll(getenv("ICM_WINO8_MINWG")) : 150;
+    if (pblocks * cdiv(d.ncot, t8) * ngroups >= w8_min || force_tco >= 2) tco = t8;
+    else w8 = false;
+  }
   d.ncb = cdiv(d.ncot, tco);
   d.npx = (int)pblocks;
   static const int dbg = getenv("ICM_WINO_DEBUG") ? atoi(getenv("ICM_WINO_DEBUG")) : 0;
@@ -473,7 +661,12 @@ int run_conv_wino(const icm_conv_args* arr, int ngroups, hipStream_t stream) {
   const long long nblk = pblocks * d.ncb;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
   void (*fn)(const WinoDesc) = tco == 2 ? conv_wino_kernel<2> : conv_wino_kernel<1>;
-  const size_t lds = (size_t)2 * WINO_STEP_FLOATS * sizeof(float);   // 64 KB: two staging steps; the output transform reuses it
+  size_t lds = (size_t)2 * WINO_STEP_FLOATS * sizeof(float);   // 64 KB: two staging steps; the output transform reuses it
+  if (w8) {
+    fn = tco == 4 ? conv_wino8_kernel<4> : (tco == 3 ? conv_wino8_kernel<3> : conv_wino8_kernel<2>);
+    lds = (size_t)2 * 4 * 2 * 2 * 16 * 64 * sizeof(float);      // 128 KB: one output-transform pass of two co tiles
+    if (!ensure_max_lds(reinterpret_cast<const void*>(fn))) return ICM_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(fn, dim3((unsigned)nblk, ngroups, 1), dim3(512), lds, stream, d);
   ICM_CHECK_LAUNCH();
   return ICM_OK;

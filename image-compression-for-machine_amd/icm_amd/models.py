@@ -167,14 +167,15 @@ def _copy_op(tape, src, dst):
         tape.bw.append(bwd)
 
 
-# ICM_SLICE_SPLIT=1: the first layer of every slice chain is split by input-channel block (slices.py): the latent
-# block of all 3 * num_slices chains runs as two wide convolutions outside the serial slice loop.  0 (default) = the
-# per-chain form below (support buffers, cat -> chain).  Both are kept and both are parity-tested; the default is the
-# one that measured faster on MI355X in same-box A/B runs (round 3, with the Winograd kernels: 358.2 vs 354.9 img/s at
-# B=16; 348.0 vs 337.3 with the pre-transformed operands -- the split form's wide launches have few output tiles and
-# its support / own-slice blocks add ~30 small launches per direction).
+# ICM_SLICE_SPLIT=1 (default): the first layer of every slice chain is split by input-channel block (slices.py): the
+# latent block of all 3 * num_slices chains runs as two wide convolutions outside the serial slice loop.  0 = the
+# per-chain form below (support buffers, cat -> chain).  Both are kept and both are parity-tested at the bench geometry.
+# Same-box A/B on MI355X (round 3, B=16): with the direct kernels only the split form LOSES (329.7 vs 335.7 img/s: its
+# wide launches have few output tiles, and the support / own-slice blocks add ~30 small launches per direction); with
+# the eight-wave Winograd kernel, whose wide co blocks are exactly what the 4 256-channel latent launch wants (460 us,
+# 218 TF algorithmic), training is a tie (370.9 vs 371.8) and the eval forward gains 3 % (1 216 vs 1 180 img/s).
 import os as _os
-SLICE_SPLIT = _os.environ.get("ICM_SLICE_SPLIT", "0") != "0"
+SLICE_SPLIT = _os.environ.get("ICM_SLICE_SPLIT", "1") != "0"
 
 
 def hyper_slices(tape: E.Tape, P: Dict[str, torch.Tensor], y: torch.Tensor, noise_z, noise_y, num_slices: int,
