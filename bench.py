@@ -12,6 +12,9 @@ backward, clip_grad_norm_(1.0), Adam on the 75.2 M parameters, aux loss + Adam o
 per GPU (BASELINE.json configs[1]; configs[2] = 8 GPUs x 16).  Prints ONE JSON line:
 
   value / ms_per_step   whole-job images/s over the timed region (barrier + synchronize on both sides, max over ranks)
+  forward / stf         (1 GPU, cnn line only) sub-objects: eval forward of the same model on the same batch, and the stf
+                        model's training step + eval forward, each {value, ms_per_step, roofline_step}
+  dist                  backend and world size the collective layer saw (RCCL = "nccl")
   roofline_step         the whole step against the f32-MFMA roofline (206.6 GFLOP / image)
   roofline              the kernel FAMILY (implicit-GEMM conv = forward + input gradients | weight gradients) that is
                         furthest below the roofline among those with >= 15 % of the step's kernel time: algorithmic
@@ -323,9 +326,9 @@ def main():
             line["forward"] = forward_bench("cnn", tr.params(), x)
             try:
                 tr2, x2, _ = make_workload("stf", dev, rank)
-                ms2 = timed(lambda: tr2.step(x2), 3, 8)
+                ms2 = timed(lambda: tr2.step(x2), 5, 10)   # (step 1 records the packing sequence, step 2 replays it: 5 warm-ups)
                 ips2 = BATCH_PER_GPU / ms2 * 1e3
-                line["stf"] = {"train": {"value": ips2, "unit": "images/s", "ms_per_step": ms2, "steps": 8, "warmup": 3,
+                line["stf"] = {"train": {"value": ips2, "unit": "images/s", "ms_per_step": ms2, "steps": 10, "warmup": 5,
                                          "batch": BATCH_PER_GPU, "roofline_step": roofline_of(ips2, 3 * 67.0)},
                                "forward": forward_bench("stf", tr2.params(), x2)}
                 del tr2, x2
