@@ -13,7 +13,7 @@ WHAT = {
              4 * (16 * 192 * 128 * 128 + 16 * 192 * 64 * 64 + 192 * 192 * 25), 2.0 * 16 * 192 * 192 * 25 * 64 * 64),
     # Winograd kernels (round 3): algorithmic bytes / FLOP of the DIRECT form of the same problem (what the launch
     # computes); the kernel executes 4/9 of the multiply-adds and moves the 16-point weights / transformed operands
-    "wino": ("conv_wino", "conv_wino_kernel", "slice-chain second layer conv3x3 224->176 on [16,224,16,16] x 10 members (Winograd F(2x2,3x3))",
+    "wino": ("conv_wino", "conv_wino", "slice-chain second layer conv3x3 224->176 on [16,224,16,16] x 10 members (Winograd F(2x2,3x3))",
              10 * 4 * (16 * 224 * 256 + 16 * 176 * 256 + 176 * 224 * 9), 2.0 * 9 * 10 * 16 * 256 * 224 * 176),
     "wwino": ("wgrad_wino", "wgrad_wino_kernel", "slice-chain first-layer wgrad 3x3 512->224 on [16,512,16,16] x 5 problems (Winograd)",
               5 * 4 * (16 * 512 * 256 + 16 * 224 * 256 + 224 * 512 * 9), 2.0 * 9 * 5 * 16 * 256 * 512 * 224),
