@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include "icm_common.h"
 
 namespace icm {
@@ -26,6 +27,18 @@ namespace icm {
 #define WW_ROW 68                      /* floats per (xi, tile) row: 64 channels + 4 (bank spreading) */
 #define WW_SIDE (16 * 8 * WW_ROW)      /* one operand of one chunk */
 #define WW_BUF (2 * WW_SIDE)           /* dM + V of one chunk */
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ww_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ww_static_for<I + 1, N>(f);
+  }
+}
 
 struct WwPtrs {
   const float* gs;   // dY [N][Ca][H][W]
@@ -42,6 +55,7 @@ struct WwDesc {
   int ntiles, nchunks, nsplit, natile, nbtile;
 };
 
+template <bool VEC>
 __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WwDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -61,7 +75,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WwDesc d) {
   const bool aok = a0 + ch_l < d.Ca, bok = b0 + ch_l < d.Cb;
   const int offa = (a0 + ch_l) * HW, offb = (b0 + ch_l) * HW;   // element offsets from the (uniform) tensor bases: < 2^29 (host-checked)
   float bsum = 0.0f;
-  auto load = [&](float (&ra)[4], float (&rb)[16], int it) {
+
+  // ---- gather state.  ONE register set (4 + 16 floats) holds the raw dY / x values of one chunk, plus a validity mask.
+  // The gathers are straight-line code: an invalid piece (image border, channel / tile past the end) reads element 0 of
+  // its tensor instead and is zeroed by the mask at transform time -- no exec-masked regions, so the loads go straight
+  // to their destination registers and the only vmcnt wait is at their first use, a whole multiply later.
+  // VEC (even W >= 4, host-checked): a tile's two dY rows are 8-byte pairs and its four x rows 16-byte runs, one load
+  // instruction each: 6 gather instructions per thread and chunk instead of 20 (the address path of the CU, not the
+  // matrix pipe, bounded the dword version).  At the left / right image border the run is shifted by one column to
+  // stay inside the row and the patch is picked out of it at transform time (mask bits 8 / 9).
+  f32x2 ya[2];
+  f32x4 xb[4];
+  unsigned vmask = 0;           // VEC: bit r = dY row r, bit 2 + r = x row r, 8 = left border, 9 = right border
+  //                               else: bit 2 r + c = dY element, bit 4 + 4 r + c = x element
+  unsigned oa_cur = 0, ob_cur = 0;
+  auto prep = [&](int it) {     // addresses + mask of chunk `it` (past the end: mask 0) for this thread's (channel, tile)
     const int tau = (split + it * d.nsplit) * 8 + tl;
     const uint32_t q = fdiv((uint32_t)tau, d.dTW);
     const int tx = tau - (int)q * d.TW;
@@ -69,63 +97,122 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WwDesc d) {
     const int ty = (int)(q - n * (uint32_t)d.TH);
     const bool tok = tau < d.ntiles;
     const int oy = ty * 2, ox = tx * 2;
-    const float* pa = G.gs + (unsigned)(offa + (int)n * (int)d.gs_bs + oy * d.W + ox);
+    oa_cur = (unsigned)(offa + (int)n * (int)d.gs_bs + oy * d.W + ox);
+    unsigned m = 0;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < 2; ++r) m |= (unsigned)(tok && aok && oy + r < d.H) << r;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-        ra[r * 2 + c] = (tok && aok && oy + r < d.H && ox + c < d.W) ? pa[r * d.W + c] : 0.0f;
-    const int ob = offb + (int)n * (int)d.gb_bs + (oy - 1) * d.W + (ox - 1);   // may be "negative" at the image border: masked
+      for (int r = 0; r < 4; ++r) m |= (unsigned)(tok && bok && (unsigned)(oy - 1 + r) < (unsigned)d.H) << (2 + r);
+      const bool left = ox == 0, right = ox == d.W - 2;
+      m |= (unsigned)left << 8 | (unsigned)right << 9;
+      ob_cur = (unsigned)(offb + (int)n * (int)d.gb_bs + (oy - 1) * d.W + (ox - 1) + (left ? 1 : (right ? -1 : 0)));
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int iy = oy - 1 + r, ix = ox - 1 + c;
-        rb[r * 4 + c] = (tok && bok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) ? G.gb[(unsigned)(ob + r * d.W + c)] : 0.0f;
-      }
+        for (int c = 0; c < 2; ++c) m |= (unsigned)(tok && aok && oy + r < d.H && ox + c < d.W) << (2 * r + c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          m |= (unsigned)(tok && bok && (unsigned)(oy - 1 + r) < (unsigned)d.H && (unsigned)(ox - 1 + c) < (unsigned)d.W) << (4 + 4 * r + c);
+      ob_cur = (unsigned)(offb + (int)n * (int)d.gb_bs + (oy - 1) * d.W + (ox - 1));
+    }
+    vmask = m;
   };
-  auto transform_store = [&](const float (&ra)[4], const float (&rb)[16], int buf) {
-    float* da = smem + buf * WW_BUF + tl * WW_ROW + ch_l;
-    float* db = da + WW_SIDE;
-    {   // dM = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
-      float y[4];
+  auto piece = [&](auto kc) {   // k = 0, 1: dY rows; 2..5: x rows
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < 2) {
+      constexpr int r = k;
+      if constexpr (VEC) {
+        const unsigned off = (vmask >> r & 1u) ? oa_cur + r * d.W : 0u;
+        const f32x2u v = *reinterpret_cast<const f32x2u*>(G.gs + off);
+        ya[r] = f32x2{v[0], v[1]};
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] = ra[e];   // (activation-free operands only: host-checked)
+        for (int c = 0; c < 2; ++c) ya[r][c] = G.gs[(vmask >> (2 * r + c) & 1u) ? oa_cur + r * d.W + c : 0u];
+      }
+    } else {
+      constexpr int r = k - 2;
+      if constexpr (VEC) {
+        const unsigned off = (vmask >> (2 + r) & 1u) ? ob_cur + r * d.W : 0u;
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(G.gb + off);
+        xb[r] = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[r][c] = G.gb[(vmask >> (4 + 4 * r + c) & 1u) ? ob_cur + r * d.W + c : 0u];
+      }
+    }
+  };
+  // ---- transform, in two steps: rowpass() consumes the register set (so the next gathers can be issued right away) and
+  // leaves A dY (8 values) and B^T d (16 values); store_part<g>() finishes one row of either (second factor + 4 LDS
+  // stores) -- eight parts, one per MFMA group of the multiply below.
+  float tY[4][2], uX[16];
+  auto rowpass = [&]() {
+    {   // dM = A dY A^T,  A = [[1,0],[1,1],[1,-1],[0,-1]]
+      float y[4];   // (activation-free operands only: host-checked)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) y[2 * r + c] = (vmask >> (VEC ? r : 2 * r + c) & 1u) ? ya[r][c] : 0.0f;
       bsum += (y[0] + y[1]) + (y[2] + y[3]);
-      float t[4][2];   // A dY
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        t[0][c] = y[0 * 2 + c];
-        t[1][c] = y[0 * 2 + c] + y[1 * 2 + c];
-        t[2][c] = y[0 * 2 + c] - y[1 * 2 + c];
-        t[3][c] = -y[1 * 2 + c];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        da[(i * 4 + 0) * 8 * WW_ROW] = t[i][0];
-        da[(i * 4 + 1) * 8 * WW_ROW] = t[i][0] + t[i][1];
-        da[(i * 4 + 2) * 8 * WW_ROW] = t[i][0] - t[i][1];
-        da[(i * 4 + 3) * 8 * WW_ROW] = -t[i][1];
+        tY[0][c] = y[0 * 2 + c];
+        tY[1][c] = y[0 * 2 + c] + y[1 * 2 + c];
+        tY[2][c] = y[0 * 2 + c] - y[1 * 2 + c];
+        tY[3][c] = -y[1 * 2 + c];
       }
     }
     {   // V = B^T d B
-      float dd[16], u[16];
+      float dd[16];
+      if constexpr (VEC) {
+        const bool left = vmask >> 8 & 1u, right = vmask >> 9 & 1u;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dd[e] = rb[e];
+        for (int r = 0; r < 4; ++r) {
+          const bool rok = vmask >> (2 + r) & 1u;
+          const f32x4 v = xb[r];
+          const float e0 = left ? 0.0f : (right ? v[1] : v[0]);
+          const float e1 = left ? v[0] : (right ? v[2] : v[1]);
+          const float e2 = left ? v[1] : (right ? v[3] : v[2]);
+          const float e3 = left ? v[2] : (right ? 0.0f : v[3]);
+          dd[r * 4 + 0] = rok ? e0 : 0.0f;
+          dd[r * 4 + 1] = rok ? e1 : 0.0f;
+          dd[r * 4 + 2] = rok ? e2 : 0.0f;
+          dd[r * 4 + 3] = rok ? e3 : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dd[r * 4 + c] = (vmask >> (4 + 4 * r + c) & 1u) ? xb[r][c] : 0.0f;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        u[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
-        u[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
-        u[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
-        u[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
+        uX[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
+        uX[1 * 4 + j] = dd[1 * 4 + j] + dd[2 * 4 + j];
+        uX[2 * 4 + j] = dd[2 * 4 + j] - dd[1 * 4 + j];
+        uX[3 * 4 + j] = dd[1 * 4 + j] - dd[3 * 4 + j];
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        db[(i * 4 + 0) * 8 * WW_ROW] = u[i * 4 + 0] - u[i * 4 + 2];
-        db[(i * 4 + 1) * 8 * WW_ROW] = u[i * 4 + 1] + u[i * 4 + 2];
-        db[(i * 4 + 2) * 8 * WW_ROW] = u[i * 4 + 2] - u[i * 4 + 1];
-        db[(i * 4 + 3) * 8 * WW_ROW] = u[i * 4 + 1] - u[i * 4 + 3];
-      }
+    }
+  };
+  auto store_part = [&](auto gc, int buf) {
+    constexpr int g = decltype(gc)::value;
+    float* da = smem + buf * WW_BUF + tl * WW_ROW + ch_l;
+    if constexpr (g < 4) {
+      constexpr int i = g;
+      da[(i * 4 + 0) * 8 * WW_ROW] = tY[i][0];
+      da[(i * 4 + 1) * 8 * WW_ROW] = tY[i][0] + tY[i][1];
+      da[(i * 4 + 2) * 8 * WW_ROW] = tY[i][0] - tY[i][1];
+      da[(i * 4 + 3) * 8 * WW_ROW] = -tY[i][1];
+    } else {
+      constexpr int i = g - 4;
+      float* db = da + WW_SIDE;
+      db[(i * 4 + 0) * 8 * WW_ROW] = uX[i * 4 + 0] - uX[i * 4 + 2];
+      db[(i * 4 + 1) * 8 * WW_ROW] = uX[i * 4 + 1] + uX[i * 4 + 2];
+      db[(i * 4 + 2) * 8 * WW_ROW] = uX[i * 4 + 2] - uX[i * 4 + 1];
+      db[(i * 4 + 3) * 8 * WW_ROW] = uX[i * 4 + 1] - uX[i * 4 + 3];
     }
   };
 
@@ -141,34 +228,51 @@ __global__ __launch_bounds__(512, 2) void wgrad_wino_kernel(const WwDesc d) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[x][i][j][e] = 0.0f;
   const int foff = (2 * wave) * 8 * WW_ROW + h * WW_ROW + l31;   // fragment base: xi = 2 wave, tile = h (+ 2 j), channel l31
-  auto multiply = [&](int buf) {
-    const float* pa = smem + buf * WW_BUF + foff;
+  // One chunk: 8 groups of 4 MFMAs on buffer `rd`.  Riding on them, in program order so that the address path, the LDS
+  // and the VALU work in the shadow of the matrix pipe instead of in a phase of their own: the six gather instructions of
+  // chunk it + 2 (groups 0-2, as early as possible: their data is needed at the top of the next iteration), the eight
+  // transform parts of chunk it + 1 (stores into buffer `wr`), and the fragment reads of the NEXT group.
+  auto multiply = [&](int rd, int wr) {
+    const float* pa = smem + rd * WW_BUF + foff;
     const float* pb = pa + WW_SIDE;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int o = (x * 8 + 2 * j) * WW_ROW;
-        const float a0v = pa[o], a1v = pa[o + 32], b0v = pb[o], b1v = pb[o + 32];
-        acc[x][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0v, acc[x][0][0], 0, 0, 0);
-        acc[x][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b1v, acc[x][0][1], 0, 0, 0);
-        acc[x][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0v, acc[x][1][0], 0, 0, 0);
-        acc[x][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1v, acc[x][1][1], 0, 0, 0);
+    float a0v = pa[0], a1v = pa[32], b0v = pb[0], b1v = pb[32];
+    ww_static_for<0, 8>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, x = g >> 2;
+      float na0 = 0.0f, na1 = 0.0f, nb0 = 0.0f, nb1 = 0.0f;
+      if constexpr (g < 7) {
+        constexpr int o = (((g + 1) >> 2) * 8 + 2 * ((g + 1) & 3)) * WW_ROW;
+        na0 = pa[o]; na1 = pa[o + 32]; nb0 = pb[o]; nb1 = pb[o + 32];
       }
+      if constexpr (g < 3) {
+        piece(std::integral_constant<int, 2 * g>{});
+        piece(std::integral_constant<int, 2 * g + 1>{});
+      }
+      store_part(gc, wr);
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the gathers and stores below the last MFMA)
+      acc[x][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b0v, acc[x][0][0], 0, 0, 0);
+      acc[x][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v, b1v, acc[x][0][1], 0, 0, 0);
+      acc[x][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b0v, acc[x][1][0], 0, 0, 0);
+      acc[x][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v, b1v, acc[x][1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0v = na0; a1v = na1; b0v = nb0; b1v = nb1;
+    });
   };
 
-  // one register set: the patches of chunk it + 2 are requested right after chunk it + 1 has been transformed and are
-  // consumed after the next multiply -- a whole chunk (~4 000 cycles) of latency budget without a second set of 20
-  // registers next to the 128 accumulator registers
-  float ra[4], rb[16];
-  load(ra, rb, 0);
-  transform_store(ra, rb, 0);
-  if (niter > 1) load(ra, rb, 1);
+  // Chunks past the end have an all-zero mask (they read element 0 and store zeros into the buffer nobody reads any
+  // more), so the loop body has no conditional code.  Measured on the 320 -> 224 x 30 launch
+  // (profiles/r03_tune_wgrad_wino.txt): multiplies alone 1.8 us per chunk and CU, gather issue alone 1.1 us, transform
+  // 0.4 us -- as separate phases between barriers the three simply added up (3.3 us).
+  prep(0);
+  ww_static_for<0, 6>(piece);
+  rowpass();
+  ww_static_for<0, 8>([&](auto gc) { store_part(gc, 0); });
+  prep(1);
+  ww_static_for<0, 6>(piece);
   __syncthreads();
   for (int it = 0; it < niter; ++it) {
-    multiply(it & 1);
-    if (it + 1 < niter) transform_store(ra, rb, (it + 1) & 1);
-    if (it + 2 < niter) load(ra, rb, it + 2);
+    rowpass();          // chunk it + 1 (gathered during the previous multiply)
+    prep(it + 2);
+    multiply(it & 1, (it + 1) & 1);
     __syncthreads();
   }
 
@@ -243,8 +347,10 @@ int launch_wgrad_wino(const icm_wgrad_args* arr, int n, int nsplit, int nchunks,
   const long long nblk = (long long)d.natile * d.nbtile * nsplit;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
   const size_t lds = (size_t)2 * WW_BUF * sizeof(float);
-  if (!ensure_max_lds(reinterpret_cast<const void*>(wgrad_wino_kernel))) return ICM_ERR_LAUNCH;
-  hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)nblk, n), dim3(512), lds, stream, d);
+  static const bool novec = [] { const char* e = getenv("ICM_WW_NOVEC"); return e && atoi(e) != 0; }();   // measurement only
+  auto fn = (!novec && a.W % 2 == 0 && a.W >= 4) ? wgrad_wino_kernel<true> : wgrad_wino_kernel<false>;
+  if (!ensure_max_lds(reinterpret_cast<const void*>(fn))) return ICM_ERR_LAUNCH;
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblk, n), dim3(512), lds, stream, d);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -47,17 +47,22 @@ USE_WINO_WGRAD = _os.environ.get("ICM_WINO_WGRAD", "1") != "0"
 # input transform of the Winograd convolutions as its own launch (one per distinct input tensor of a launch) + LDS-DMA
 # staging in the convolution kernel, instead of gather + transform by the kernel's loader waves per co-block
 WINO_PRE = _os.environ.get("ICM_WINO_PRE", "1") != "0"
-# problems with many pixels keep the direct nine-tap single-staging kernel (96 -> 96 @64x64 x6: 716 us direct, 832 us
-# Winograd: its 96-wide blocks fit those layers exactly and K = 65 536 pixels amortises its staging)
-_WINO_WG_MAX_PIXELS = int(_os.environ.get("ICM_WINO_WG_MAX_PIXELS", "16384"))
+# (until the gathers of the Winograd weight-gradient kernel were vectorised and interleaved with its multiplies, problems
+# with many pixels kept the direct nine-tap kernel: 96 -> 96 @64x64 x6 was 716 us direct, 832 us Winograd; now 595 us)
+_WINO_WG_MAX_PIXELS = int(_os.environ.get("ICM_WINO_WG_MAX_PIXELS", "100000"))
 _WINO_EPIS = (EPI_NONE, EPI_RES, EPI_RES_GELU, EPI_MUL_DGELU, EPI_RES_MUL_DGELU, EPI_LRP)
 
 
-def wino_ok(KH, KW, stride, pad, Cin, ps=0, conv_transposed=False, work: float = 1e30) -> bool:
+# the weight-gradient kernel has its own depth threshold (its contraction runs over the tiles, not the channels)
+_WINO_WG_MIN_C = int(_os.environ.get("ICM_WINO_WG_MIN_C", "64"))
+
+
+def wino_ok(KH, KW, stride, pad, Cin, ps=0, conv_transposed=False, work: float = 1e30, min_c=None) -> bool:
     """should this convolution launch (forward or input gradient) run on the Winograd kernel? (the epilogue kinds of both
     directions of a 3x3 stride-1 layer are all supported: icm_conv_winograd_ok).  work = N * H * W * Cin * Cout * members."""
     return (USE_WINO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not ps and not conv_transposed and
-            Cin >= _WINO_MIN_CIN and work >= _WINO_MIN_WORK and L.lib().icm_debug_forced_conv_cfg() < 0)
+            Cin >= (_WINO_MIN_CIN if min_c is None else min_c) and work >= _WINO_MIN_WORK and
+            L.lib().icm_debug_forced_conv_cfg() < 0)
 
 
 # In-place HIP updates (icm_adam_step) do not bump torch's tensor version counters: the trainer bumps this generation
@@ -432,7 +437,8 @@ def wgrad_defer(tape, gs, gb, dw, *, Ca, Cb, KH, KW, stride, pad, act_s=ACT_NONE
     if algo is None:   # Winograd form for 3x3 stride-1 problems (wgrad_wino.hip); the work of a batch is what counts, so the
         #                threshold is applied per problem with a typical batch factor folded into ICM_WINO_MIN_WORK_WG
         algo = 1 if (USE_WINO_WGRAD and act_s == ACT_NONE and act_b == ACT_NONE and   # (materialised operands only)
-                     wino_ok(KH, KW, stride, pad, min(Ca, Cb), work=float(N) * OH * OW * Ca * Cb * _WINO_WG_BATCH)
+                     wino_ok(KH, KW, stride, pad, min(Ca, Cb), work=float(N) * OH * OW * Ca * Cb * _WINO_WG_BATCH,
+                             min_c=_WINO_WG_MIN_C)
                      and N * OH * OW < _WINO_WG_MAX_PIXELS) else 0
     key = (Ca, Cb, KH, KW, stride, pad, act_s, act_b, N, OH, OW, H, W, bs(gs), bs(gb), dbias is not None, algo)
     tape.wjobs.append((key, gs, gb, dw, accum, dbias, accum_bias, dw_ld))
