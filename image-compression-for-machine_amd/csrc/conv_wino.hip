@@ -494,6 +494,11 @@ struct WinoXfDesc {
   int N, Cin, H, W, lgTX, lgTY, lgTI, tiles_x, tiles_y, nchunks, act, seg_len, seg_gap;
   FastDiv dseg;
 };
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// VEC (even W >= 4): a patch row is ONE 16-byte load (shifted by a column at the left / right image border so that it
+// stays inside the row, the patch picked out of it) instead of four dword gathers; an invalid row reads element 0 of the
+// tensor and is zeroed -- straight-line loads, a quarter of the gather instructions (the address path bounds this kernel).
+template <bool VEC>
 __global__ __launch_bounds__(256) void wino_input_transform_kernel(const WinoXfDesc d) {
   const float* x = d.x[blockIdx.y];
   float* v = d.v[blockIdx.y];
@@ -512,16 +517,44 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const WinoXfD
   const int c = chunk * 8 + ci_l;
   const bool cok = c < d.Cin && n < d.N;
   const int cp = d.seg_len ? c + (int)fdiv((uint32_t)c, d.dseg) * d.seg_gap : c;
-  const float* pc = x + ((long long)n * d.x_bs + (long long)cp * d.H * d.W + (long long)(oy - 1) * d.W + (ox - 1));
+  const long long pbase = (long long)n * d.x_bs + (long long)cp * d.H * d.W + (long long)(oy - 1) * d.W + (ox - 1);
   float dd[16], u[16];
+  if constexpr (VEC) {
+    const bool tvalid = cok && ox < d.W;
+    const bool left = ox == 0, right = ox == d.W - 2;
+    f32x4u rv[4];
+    bool rok[4];
 #pragma unroll
-  for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 4; ++dx) {
-      const int iy = oy - 1 + dy, ix = ox - 1 + dx;
-      const float val = (cok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) ? pc[dy * d.W + dx] : 0.0f;
-      dd[dy * 4 + dx] = d.act ? apply_act(val, d.act) : val;
+    for (int dy = 0; dy < 4; ++dy) {
+      rok[dy] = tvalid && (unsigned)(oy - 1 + dy) < (unsigned)d.H;
+      const long long off = rok[dy] ? pbase + dy * d.W + (left ? 1 : (right ? -1 : 0)) : 0;
+      rv[dy] = *reinterpret_cast<const f32x4u*>(x + off);
     }
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      const f32x4u w4 = rv[dy];
+      float e[4];
+      e[0] = left ? 0.0f : (right ? w4[1] : w4[0]);
+      e[1] = left ? w4[0] : (right ? w4[2] : w4[1]);
+      e[2] = left ? w4[1] : (right ? w4[3] : w4[2]);
+      e[3] = left ? w4[2] : (right ? 0.0f : w4[3]);
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const float val = rok[dy] ? e[dx] : 0.0f;
+        dd[dy * 4 + dx] = d.act ? apply_act(val, d.act) : val;
+      }
+    }
+  } else {
+    const float* pc = x + pbase;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int iy = oy - 1 + dy, ix = ox - 1 + dx;
+        const float val = (cok && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) ? pc[dy * d.W + dx] : 0.0f;
+        dd[dy * 4 + dx] = d.act ? apply_act(val, d.act) : val;
+      }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     u[0 * 4 + j] = dd[0 * 4 + j] - dd[2 * 4 + j];
@@ -575,7 +608,11 @@ int run_wino_transform(const icm_conv_args* arr, int ngroups, hipStream_t stream
   d.dseg = make_fastdiv((uint32_t)std::max(1, a.x_seg_len));
   const long long nblk = (long long)g.tiles_x * g.tiles_y * g.tiles_n * d.nchunks;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return ICM_ERR_ARG;
-  hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)nblk, ngroups), dim3(256), 0, stream, d);
+  static const bool novec = [] { const char* e = getenv("ICM_WINO_XF_NOVEC"); return e && atoi(e) != 0; }();   // measurement only
+  if (!novec && a.W % 2 == 0 && a.W >= 4)
+    hipLaunchKernelGGL(wino_input_transform_kernel<true>, dim3((unsigned)nblk, ngroups), dim3(256), 0, stream, d);
+  else
+    hipLaunchKernelGGL(wino_input_transform_kernel<false>, dim3((unsigned)nblk, ngroups), dim3(256), 0, stream, d);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }
