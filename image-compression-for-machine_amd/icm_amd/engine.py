@@ -36,7 +36,7 @@ MAX_GROUP = 12   # ICM_MAX_GROUPS of conv_common.h
 USE_WINO = _os.environ.get("ICM_WINO", "1") != "0"
 # contraction depth below which the direct kernels win even on large launches (ResidualUnit 3x3 96 -> 96 @64x64 x2:
 # 206 us direct, 255 us Winograd: six K steps do not amortise the transforms and the 16-point epilogue)
-_WINO_MIN_CIN = int(_os.environ.get("ICM_WINO_MIN_CIN", "128"))
+_WINO_MIN_CIN = int(_os.environ.get("ICM_WINO_MIN_CIN", "96"))
 # Small launches are latency-bound (prologue gather + transform, LDS round trip of the output transform): below this
 # many multiply-adds of the DIRECT form per launch / 9 (N * H * W * Cin * Cout * members) the direct kernels win
 # (measured on MI355X, profiles/r03_wino_vs_direct.txt)
