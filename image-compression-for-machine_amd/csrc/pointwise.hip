@@ -176,6 +176,20 @@ __global__ void copy_strided_kernel(const float* src, long long sbs, float* dst,
     dst[b * dbs + r] = v;
   }
 }
+// dst[b][a][k] (+)= src[a][b][K-1-k]: a Conv2d weight [Cout][Cin][KH*KW] as the ConvTranspose2d weight of the same map
+// (stride 1: conv(x, W, pad p) = convT(x, W', pad K-1-p), W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx]), and the
+// gradient of W' back into the layout of W (the same permutation with A and B exchanged)
+__global__ void permute_flip_kernel(const float* src, float* dst, int A, int B, int K, int accum) {
+  const long long n = (long long)A * B * K;
+  GRID_STRIDE(i, n) {
+    const int k = (int)(i % K);
+    const long long ab = i / K;
+    const int a = (int)(ab % A), b = (int)(ab / A);
+    float v = src[((long long)a * B + b) * K + (K - 1 - k)];
+    if (accum) v += dst[i];
+    dst[i] = v;
+  }
+}
 // dpre[n,c,p] = g[n,c,p] * 0.5 * (1 - t^2)   (LRP tail backward, cnn.py:177-178)
 __global__ void lrp_bwd_kernel(const float* g, long long gbs, const float* t, long long tbs, float* dpre, long long dbs,
                                int N, int C, int HW) {
@@ -731,6 +745,12 @@ int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_b
   if (!src || !dst || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   hipLaunchKernelGGL(copy_strided_kernel, dim3(grid_for((long long)N * C * HW)), dim3(256), 0, ST, src,
                      (long long)src_bs, dst, (long long)dst_bs, N, C, HW, accum);
+  ICM_CHECK_LAUNCH();
+  return ICM_OK;
+}
+int icm_permute_flip(const float* src, float* dst, int A, int B, int K, int accum, void* stream) {
+  if (!src || !dst || A <= 0 || B <= 0 || K <= 0 || src == dst) return ICM_ERR_ARG;
+  hipLaunchKernelGGL(permute_flip_kernel, dim3(grid_for((long long)A * B * K)), dim3(256), 0, ST, src, dst, A, B, K, accum);
   ICM_CHECK_LAUNCH();
   return ICM_OK;
 }

@@ -69,7 +69,7 @@ SYMBOLS = [
     "icm_wgrad_workspace_floats", "icm_wgrad_workspace_floats_grouped", "icm_conv_wgrad", "icm_conv_wgrad_grouped", "icm_channel_sum", "icm_nonneg_fwd", "icm_nonneg_bwd",
     "icm_gdn_bwd_pre", "icm_gelu_fwd", "icm_gate_fwd", "icm_gate_bwd", "icm_add_grad", "icm_ste_round_offset",
     "icm_lrp_bwd", "icm_pixel_unshuffle2", "icm_layernorm_fwd", "icm_layernorm_bwd", "icm_space_to_depth2",
-    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_gather_vectors", "icm_conv_winograd_ok", "icm_wino_transform_floats", "icm_wino_transform", "icm_winattn_fwd", "icm_winattn_bwd",
+    "icm_residual_scale", "icm_im2col", "icm_col2im", "icm_copy_strided", "icm_permute_flip", "icm_gather_vectors", "icm_conv_winograd_ok", "icm_wino_transform_floats", "icm_wino_transform", "icm_winattn_fwd", "icm_winattn_bwd",
     "icm_eb_likelihood_fwd", "icm_eb_likelihood_bwd", "icm_eb_aux_loss", "icm_gc_likelihood_ste_fwd",
     "icm_gc_likelihood_ste_bwd", "icm_rd_loss_fwd", "icm_rd_loss_bwd", "icm_grad_sqnorm", "icm_adam_step", "icm_adam_step_hyper", "icm_fill",
     "icm_winattn_bwd_workspace_floats", "icm_debug_force_conv_cfg", "icm_debug_forced_conv_cfg", "icm_debug_force_conv1x1",
@@ -131,6 +131,7 @@ def lib():
         L.icm_im2col.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_col2im.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_copy_strided.argtypes = [vp, i64, vp, i64, i32, i32, i32, i32, vp]
+        L.icm_permute_flip.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.icm_winattn_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_winattn_bwd.argtypes = [vp, vp, vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]
         L.icm_winattn_bwd_workspace_floats.argtypes = [i32, i32, i32, i32, i32, i32]

@@ -44,6 +44,8 @@ _WINO_MIN_WORK = float(_os.environ.get("ICM_WINO_MIN_WORK", "2.0e8"))
 # weight gradients are issued in batches of same-geometry problems (flush_wgrads): a single problem counts this many times
 _WINO_WG_BATCH = float(_os.environ.get("ICM_WINO_WG_BATCH", "4"))
 USE_WINO_WGRAD = _os.environ.get("ICM_WINO_WGRAD", "1") != "0"
+# stride-1 Conv2d layers with <= 8 output channels (stf end_conv[2]) as a dense (channel, tap)-row GEMM + col2im
+THIN_OUT = _os.environ.get("ICM_THIN_OUT", "1") != "0"
 # input transform of the Winograd convolutions as its own launch (one per distinct input tensor of a launch) + LDS-DMA
 # staging in the convolution kernel, instead of gather + transform by the kernel's loader waves per co-block
 WINO_PRE = _os.environ.get("ICM_WINO_PRE", "1") != "0"
@@ -267,12 +269,15 @@ class Tape:
             self._ws = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
         return self._ws
 
-    def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0, wino=0):
+    def pack(self, w, M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg=0, bound=0.0, ped=0.0, wino=0,
+             log: bool = True):
         """MFMA-fragment-order copy of a weight for this step (one packing job; see pack_entry).
-        wino: 1 / 2 = Winograd-domain weights (forward / input-gradient orientation) of a 3x3 stride-1 kernel."""
+        wino: 1 / 2 = Winograd-domain weights (forward / input-gradient orientation) of a 3x3 stride-1 kernel.
+        log=False: w is a per-step temporary (conv2d_thin_out): it is packed on demand only, never ahead of time from the
+        sequence a previous step recorded."""
         args = (M, K, KH, KW, src_out_major, transposed, stride, pad, nonneg, float(bound), float(ped), 0, 0, 0, 0, wino)
         floats = L.lib().icm_packed_weight_floats(M, K, 4, 4) if wino else L.lib().icm_packed_weight_floats(M, K, KH, KW)
-        return self.pack_entry(((w.data_ptr(),), (args,)), floats, [(w, args, 0)])
+        return self.pack_entry(((w.data_ptr(),), (args,)), floats, [(w, args, 0)], log=log)
 
     def pack_cat(self, members, M, K, KH, KW, src_out_major, transposed, stride, pad, axis: str, wino=0):
         """ONE packed buffer holding sub-matrices of several weights laid end to end along a GEMM axis, so that a single
@@ -306,7 +311,7 @@ class Tape:
             argl.append(a)
         return self.pack_entry((tuple(ids), tuple(argl), axis), n * per, jobs)
 
-    def pack_entry(self, ident, floats, jobs):
+    def pack_entry(self, ident, floats, jobs, log: bool = True):
         """ident: hashable, stable across steps (weight addresses + job arguments); jobs: [(w, args16, float offset)].
         With ``pack_seq`` (the miss sequence recorded on an earlier, identical step) a miss packs a short WINDOW of
         upcoming entries in one launch: the ~830 tiny per-layer pack launches of a training step become ~40, while every
@@ -317,10 +322,10 @@ class Tape:
         wp = self._packed.get(k)
         if wp is not None:
             return wp
-        if self.pack_log is not None:
+        if self.pack_log is not None and log:
             self.pack_log.append((ident, floats, jobs))
         todo = [(k, floats, jobs)]
-        seq = self.pack_seq
+        seq = self.pack_seq if log else None
         if seq is not None:
             i = self._seq_pos.get(ident) if self._seq_pos is not None else None
             if i is not None:
@@ -530,12 +535,15 @@ def copy_into(tape, src, dst, accum=0):
 
 # ------------------------------------------------------------------------------------------------ conv family
 def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, output_padding=0, res: Optional[VT] = None,
-           out=None, pixel_shuffle=0, lrp_aux=None, w_as: Optional[Tuple[int, int]] = None,
+           out=None, pixel_shuffle=0, lrp_aux=None, w_as: Optional[Tuple[int, int]] = None, temp_weight: bool = False,
            act_out: bool = False) -> torch.Tensor:
     """nn.Conv2d / nn.ConvTranspose2d / nn.Linear(on NCHW) forward with fused neighbours.  Returns the
     pre-activation output tensor (or y_hat for the LRP epilogue).  w_as=(d0, d1): use the (contiguous) weight as a
     [d0, d1, 1, 1] matrix (thin-channel layers run as 1x1 GEMMs over (channel, tap) pairs); gradients still land in
-    the weight's own buffer.  act_out: the consumers of the result apply GELU -- store gelu(y) next to y (tape.mat)."""
+    the weight's own buffer.  act_out: the consumers of the result apply GELU -- store gelu(y) next to y (tape.mat).
+    temp_weight: w is a per-step temporary derived from a parameter (conv2d_thin_out): its packed copies are never
+    produced ahead of time from a recorded sequence and its gradient is computed at once on the main stream (the caller
+    carries it back into the parameter's layout right behind this layer's backward)."""
     x, act = xv.t, xv.act
     xf, actf = _operand(tape, xv)       # what the forward kernel and the weight gradient read
     N, Cin, H, W = x.shape
@@ -547,12 +555,12 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
         Cout, ci, KH, KW = w4.shape
         OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
         wino = 1 if wino_ok(KH, KW, stride, pad, Cin, pixel_shuffle, work=float(N) * OH * OW * Cin * Cout) and w_as is None else 0
-        wp = tape.pack(w4, Cout, Cin, KH, KW, 1, 0, stride, pad, wino=wino)
+        wp = tape.pack(w4, Cout, Cin, KH, KW, 1, 0, stride, pad, wino=wino, log=not temp_weight)
     else:
         ci, Cout, KH, KW = w4.shape
         OH = (H - 1) * stride - 2 * pad + KH + output_padding
         OW = (W - 1) * stride - 2 * pad + KW + output_padding
-        wp = tape.pack(w4, Cout, Cin, KH, KW, 0, 1, stride, pad)
+        wp = tape.pack(w4, Cout, Cin, KH, KW, 0, 1, stride, pad, log=not temp_weight)
     if ci != Cin:
         raise ValueError(f"conv2d: weight expects {ci} input channels, got {Cin}")
     if pixel_shuffle == 2:
@@ -602,13 +610,14 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             channel_sum(tape, dy, gb_, acc)
         if tape.wants(w):
             gw, acc = tape.grad_for_write(w)
+            wg = wgrad_launch if temp_weight else wgrad_defer
             if not transposed:
                 gb_, accb = tape.grad_for_write(b) if fuse_b else (None, 0)
-                wgrad_defer(tape, dy, xf, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=actf,
-                            accum=acc, dbias=gb_, accum_bias=accb)
+                wg(tape, dy, xf, gw, Ca=Cout, Cb=Cin, KH=KH, KW=KW, stride=stride, pad=pad, act_b=actf,
+                   accum=acc, dbias=gb_, accum_bias=accb)
             else:
-                wgrad_defer(tape, xf, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=actf,
-                            accum=acc)
+                wg(tape, xf, dy, gw, Ca=Cin, Cb=Cout, KH=KH, KW=KW, stride=stride, pad=pad, act_s=actf,
+                   accum=acc)
         if tape.wants(x):
             rg = tape.take_res_grad(x, act == ACT_GELU) if act in (ACT_GELU, ACT_NONE) else None
             gx, acc = tape.grad_for_write(x)
@@ -621,12 +630,12 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
             if not transposed:   # conv dgrad = scatter with W ([K=Cout][M=Cin])
                 wb = 2 if (wino_ok(KH, KW, stride, pad, Cout, pixel_shuffle, work=float(N) * H * W * Cin * Cout)
                            and w_as is None) else 0
-                wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad, wino=wb)
+                wpb = tape.pack(w4, Cin, Cout, KH, KW, 0, 1, stride, pad, wino=wb, log=not temp_weight)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
                             transposed=1, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc, tag="dgrad",
                             algo=1 if wb else 0)
             else:                # convT dgrad = gather with Wt ([M=Cin][K=Cout])
-                wpb = tape.pack(w4, Cin, Cout, KH, KW, 1, 0, stride, pad)
+                wpb = tape.pack(w4, Cin, Cout, KH, KW, 1, 0, stride, pad, log=not temp_weight)
                 conv_launch(tape, dy, wpb, None, gx, Cin=Cout, Cout=Cin, KH=KH, KW=KW, stride=stride, pad=pad,
                             transposed=0, OH=H, OW=W, epi=epi_b, aux=aux_b, res=rg, accum=acc, tag="dgrad")
 
@@ -661,7 +670,7 @@ def conv2d_thin_in(tape: Tape, x, w, b, *, stride, pad) -> torch.Tensor:
     return conv2d(tape, VT(cols), w, b, w_as=(Cout, Cin * K * K))
 
 
-def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -> torch.Tensor:
+def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding, temp_weight: bool = False) -> torch.Tensor:
     """ConvTranspose2d with very few output channels (g_s.8: 192 -> 3, 5x5 s2; cnn.py:51) as a 1x1 GEMM producing the
     Cout*K*K per-tap contributions of every input pixel, then one col2im pass (+ bias)."""
     x = xv.t
@@ -671,7 +680,7 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
         raise ValueError("convT2d_thin_out: weight / input mismatch")
     OH = (H - 1) * stride - 2 * pad + K + output_padding
     OW = (W - 1) * stride - 2 * pad + K + output_padding
-    tmp = conv2d(tape, xv, w, None, transposed=True, stride=1, pad=0, w_as=(Cin, Cout * K * K))
+    tmp = conv2d(tape, xv, w, None, transposed=True, stride=1, pad=0, w_as=(Cin, Cout * K * K), temp_weight=temp_weight)
     out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
     check(L.lib().icm_col2im(ptr(tmp), ptr(b), ptr(out), N, Cout, OH, OW, K, stride, pad, 0, tape.st), "col2im")
     if tape.need_grad:
@@ -688,6 +697,41 @@ def convT2d_thin_out(tape: Tape, xv: VT, w, b, *, stride, pad, output_padding) -
             check(L.lib().icm_im2col(ptr(dy), ptr(dt), N, Cout, OH, OW, K, stride, pad, tape.st), "im2col")
         tape.bw.append(bwd)
     return out
+
+
+def conv2d_thin_out(tape: Tape, xv: VT, w, b, *, pad) -> torch.Tensor:
+    """Stride-1 Conv2d with very few output channels (stf.py:401-404, end_conv[2]: 48 -> 3, 3x3 on the full-resolution
+    map).  The implicit-GEMM kernels pad the 3 output channels to a 32-row tile per tap (forward 8 TF, weight gradient
+    3 TF: 0.86 ms for 5 GFLOP); as the ConvTranspose2d of the same map -- W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx],
+    pad' = K-1-pad -- it takes the thin-output path: one dense 1x1 GEMM with Cout*K*K = 27 rows + col2im.  W' is a
+    per-step temporary (icm_permute_flip); its gradient is computed at once and carried back into W's layout by the same
+    permutation, so the parameter's gradient is complete when this layer's backward returns (bucketed all-reduce)."""
+    Cout, Cin, K, K2 = w.shape
+    if K != K2 or not (0 <= pad <= K - 1):
+        raise ValueError("conv2d_thin_out: square kernel and 0 <= pad <= K-1 expected")
+    # eval with a packed cache: the permuted copy lives as long as the packed weights.  With gradients every call gets
+    # its own copy (its own gradient buffer: a weight shared by two layers accumulates once per layer).
+    ck = ("thin_wt", w.data_ptr(), w._version, _weight_gen[0])
+    wt = None if tape.need_grad else tape._packed.get(ck)
+    if wt is None:
+        wt = torch.empty((Cin, Cout, K, K), dtype=torch.float32, device=w.device)
+        wc = w if w.is_contiguous() else w.contiguous()
+        check(L.lib().icm_permute_flip(ptr(wc), ptr(wt), Cout, Cin, K * K, 0, tape.st), "permute_flip")
+        if not tape.need_grad:
+            tape._packed[ck] = wt
+    if tape.need_grad:
+        if tape.wants(w):
+            def bwd_w():                # registered first = runs after the backward of the layer below
+                g = tape.grad_of(wt)
+                if g is None:
+                    return
+                gw, acc = tape.grad_for_write(w)
+                assert gw.is_contiguous() and g.is_contiguous()
+                check(L.lib().icm_permute_flip(ptr(g), ptr(gw), Cin, Cout, K * K, acc, tape.st), "permute_flip")
+            tape.bw.append(bwd_w)
+        else:
+            tape.stop(wt)
+    return convT2d_thin_out(tape, xv, wt, b, stride=1, pad=K - 1 - pad, output_padding=0, temp_weight=True)
 
 
 def conv_launch_grouped(tape, xs, wps, biases, ys, *, Cin, Cout, KH, KW, stride, pad, transposed, OH, OW,

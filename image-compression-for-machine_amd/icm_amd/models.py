@@ -492,6 +492,8 @@ def stf_synthesis(tape: E.Tape, P, Y_hat, drops=None, window: int = 4):
                          "split" if i < 3 else None, drops)
     # ---- end_conv (stf.py:401-404): conv5x5 -> PixelShuffle(2) (fused store) -> conv3x3
     t = E.conv2d(tape, VT(t), P["end_conv.0.weight"], P["end_conv.0.bias"], pad=2, pixel_shuffle=2)
+    if E.THIN_OUT:   # 48 -> 3 output channels: dense 27-row GEMM + col2im instead of a 32-row tile per tap
+        return E.conv2d_thin_out(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
     return E.conv2d(tape, VT(t), P["end_conv.2.weight"], P["end_conv.2.bias"], pad=1)
 
 

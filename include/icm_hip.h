@@ -198,6 +198,10 @@ int icm_pixel_unshuffle2(const float* src, float* dst, int N, int C, int H, int 
 int icm_gather_vectors(const float* const* srcs, int n, int len, float* dst, void* stream);
 /* strided 4-D copy (chunk/cat plumbing): dst[n,c,p] (+)= src[n,c,p] */
 int icm_copy_strided(const float* src, int64_t src_bs, float* dst, int64_t dst_bs, int N, int C, int HW, int accum, void* stream);
+/* dst[b][a][k] (+)= src[a][b][K-1-k]  (src [A][B][K], dst [B][A][K]): a Conv2d weight [Cout][Cin][KH*KW] (reference:
+ * torch.nn.Conv2d in stf.py:401-404 `end_conv`) rewritten as the ConvTranspose2d weight of the same stride-1 map, and
+ * that weight's gradient carried back; used by the thin-output path (very few output channels) of the host layer. */
+int icm_permute_flip(const float* src, float* dst, int A, int B, int K, int accum, void* stream);
 
 /* ---- zigzag block ordering of the stf6 / oj_ICM variants (compressai/models/stf6.py:654-762; fasterRCNN_ICM.py:103-293)
  * The latent x [B,C,H,W] (batch stride x_bs) is a grid of num_slices x num_h x num_w contiguous blocks; the zigzag

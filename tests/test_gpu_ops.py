@@ -430,6 +430,47 @@ def test_convT_thin_out_vs_torch(shape):
     close(gb, gbr, what="gb", tol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 48, 20, 24, 3, 3, 1), (1, 16, 9, 11, 2, 3, 0), (2, 24, 12, 12, 5, 5, 2), (1, 8, 6, 7, 1, 1, 0)])
+def test_conv_thin_out_vs_torch(shape):
+    """stf end_conv[2]-style stride-1 Conv2d (few OUTPUT channels; stf.py:401-404) as the ConvTranspose2d of the same
+    map on the flipped / transposed weight (icm_permute_flip) through the thin-output path: forward, dgrad, wgrad carried
+    back into the Conv2d weight layout, bias grad; a second call accumulates into an existing weight gradient"""
+    from icm_amd import engine as E
+    from icm_amd.engine import VT
+    N, Cin, H, Wd, Cout, k, p = shape
+    x = U("thinO.x", (N, Cin, H, Wd), -1.0, 1.0)
+    w = U("thinO.w", (Cout, Cin, k, k), -0.3, 0.3)
+    b = U("thinO.b", (Cout,), -0.5, 0.5)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=1, padding=p)
+    g = U("thinO.g", yr.shape, -1.0, 1.0)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], g)
+    y, (gx, gw, gb) = _tape_run(lambda t, xx, ww, bb: E.conv2d_thin_out(t, VT(xx), ww, bb, pad=p), [x, w, b], g)
+    assert tuple(y.shape) == tuple(yr.shape)
+    close(y, yr, what="y")
+    close(gx, gxr, what="gx")
+    close(gw, gwr, what="gw", tol=1e-4)
+    close(gb, gbr, what="gb", tol=1e-4)
+    # the same layer applied twice on one tape (weight sharing): the second backward ACCUMULATES into dW
+    def twice(t, xx, ww, bb):
+        y1 = E.conv2d_thin_out(t, VT(xx), ww, bb, pad=p)
+        y2 = E.conv2d_thin_out(t, VT(xx), ww, bb, pad=p)
+        out = E.new(y1)
+        out.copy_(y1 + y2)          # (test plumbing only)
+        def bwd():
+            go = t.grad_of(out)
+            for yy in (y1, y2):
+                gy, acc = t.grad_for_write(yy)
+                assert acc == 0
+                gy.copy_(go)
+        t.bw.append(bwd)
+        return out
+    _, (gx2, gw2, gb2) = _tape_run(twice, [x, w, b], g)
+    close(gw2, 2 * gwr, what="gw x2", tol=1e-4)
+    close(gx2, 2 * gxr, what="gx x2")
+    close(gb2, 2 * gbr, what="gb x2", tol=1e-4)
+
+
 def test_conv_group_shared_input_and_lrp_tail_vs_singles():
     """conv2d_group with members sharing one input (the fixed support of the late slices) and with the LRP tail fused
     must equal the same convolutions issued one by one (forward values, input / weight / bias / aux gradients)."""

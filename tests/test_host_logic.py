@@ -208,9 +208,14 @@ def test_trainer_step_plumbing_dry_run(dry, name):
     assert s1.shape == (8,) and tr._pack_seq is not None and len(tr._pack_seq) > 100
     # step 1 packs entry by entry (one batch call per cache miss) and records the miss sequence ...
     first = dry.calls["icm_pack_weights_batch"]
-    assert first == len(tr._pack_seq) and "icm_pack_weights" not in dry.calls
+    # (stf: + the two on-demand packs -- forward and input-gradient orientation -- of the thin-output temporary of
+    # end_conv[2], engine.conv2d_thin_out: a per-step tensor is never packed ahead of time from a recorded sequence)
+    temps = 2 if name == "stf" else 0
+    assert first == len(tr._pack_seq) + temps and "icm_pack_weights" not in dry.calls
     tr.step(x)
     # ... step 2 replays it in windows of 24 entries
-    assert dry.calls["icm_pack_weights_batch"] - first == -(-len(tr._pack_seq) // 24)
+    assert dry.calls["icm_pack_weights_batch"] - first == -(-len(tr._pack_seq) // 24) + temps
     assert dry.calls["icm_adam_step"] == 4 and dry.calls["icm_grad_sqnorm"] == 2 and dry.calls["icm_eb_aux_loss"] == 2
     assert dry.calls["icm_rd_loss_fwd"] == 2 and dry.calls["icm_conv_wgrad_grouped"] > 40
+    if name == "stf":   # thin-output end_conv[2]: W -> W' and dW' -> dW once per step, its gradient computed at once
+        assert dry.calls.get("icm_permute_flip") == 4 and dry.calls.get("icm_conv_wgrad") == 2
