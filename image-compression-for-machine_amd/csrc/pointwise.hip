@@ -84,6 +84,25 @@ __global__ void split_sum_finish_kernel(const float* __restrict__ ws, float* __r
   *o = accum ? *o + s : s;
 }
 
+// the same sum for MANY partials (S up to ~1000 rows: one per workgroup of the fused LayerNorm backward): one wave per
+// output, lane l adds rows l, l + 64, ... in order, then a fixed xor tree over the lanes -- deterministic, and 64 loads
+// in flight per output instead of one serial chain of S dependent additions (which cost 0.1 ms per launch at S = 1024)
+__global__ __launch_bounds__(256) void split_sum_finish_wave_kernel(const float* __restrict__ ws, float* __restrict__ out0,
+                                                                    float* __restrict__ out1, int C, int S, int K,
+                                                                    int accum) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= C * K) return;   // wave-uniform
+  const int k = i / C, c = i - k * C;
+  float s = 0.0f;
+  for (int j = lane; j < S; j += 64) s += ws[((long long)k * S + j) * C + c];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    float* o = (k == 0 ? out0 : out1) + c;
+    *o = accum ? *o + s : s;
+  }
+}
+
 // ---------------------------------------------------------------- NonNegativeParametrizer
 __global__ void nonneg_fwd_kernel(const float* p, float* out, long long n, float bound, float ped) {
   GRID_STRIDE(i, n) {
@@ -300,22 +319,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
   }
 }
-// Register-cached variants for C = 4 * CPT <= 192 (stf levels 0-2 and patch_embed): every thread keeps its CPT channel
-// values of x (and dy) in registers, so each tensor is read from HBM once instead of three times.
-template <int CPT>
-__global__ __launch_bounds__(256) void layernorm_fwd_cached_kernel(const float* __restrict__ x, long long xbs,
-                                                                   const float* __restrict__ gamma,
-                                                                   const float* __restrict__ beta,
-                                                                   float* __restrict__ y, long long ybs,
-                                                                   float* __restrict__ mean, float* __restrict__ rstd,
-                                                                   int N, int HW, float eps) {
-  constexpr int C = 4 * CPT;
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// Register-cached variants for C = NW * CPT in {48, 96, 192, 384} (all stf levels and patch_embed): NW waves per
+// workgroup, wave cs holds channels cs, cs + NW, ... of 64 pixels; every thread keeps its CPT channel values of x (and
+// dy) in registers, so each tensor is read from HBM once instead of three times.  With FUSE the backward kernel also
+// carries the parameter gradients: every lane accumulates dy * xhat and dy of its channels over all tiles of its
+// workgroup, one cross-lane sum at the end, partials pws[{gamma, beta}][workgroup][c] for split_sum_finish_kernel
+// (fixed order) -- the separate pass over x and dy of layernorm_bwd_params_kernel is gone for C <= 192 (CPT <= 24; at
+// C = 384 the 2 x 48 extra accumulators do not fit next to the 96 cached values: that level keeps the separate pass).
+template <int VW>
+__device__ __forceinline__ float ln_sum_waves(const float (*red)[64], int px) {
+  float t[VW];
+#pragma unroll
+  for (int v = 0; v < VW; ++v) t[v] = red[v][px];
+#pragma unroll
+  for (int w = 1; w < VW; w *= 2)
+#pragma unroll
+    for (int v = 0; v + w < VW; v += 2 * w) t[v] += t[v + w];   // fixed pairwise order
+  return t[0];
+}
+template <int CPT, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_fwd_cached_kernel(const float* __restrict__ x, long long xbs,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta,
+                                                                      float* __restrict__ y, long long ybs,
+                                                                      float* __restrict__ mean, float* __restrict__ rstd,
+                                                                      int N, int HW, float eps) {
+  constexpr int VW = NW, LW = 64, C = VW * CPT;
+  __shared__ float red[VW][LW];
+  const int lane = threadIdx.x & 63, px = lane;
+  const int vs = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long total = (long long)N * HW;
-  const long long ntiles = (total + 63) / 64;
+  const long long ntiles = (total + LW - 1) / LW;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long i = tile * 64 + lane;
+    const long long i = tile * LW + px;
     const bool valid = i < total;
     const int n = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (long long)n * HW) : 0;
     const float* xp = x + n * xbs + p;
@@ -323,12 +359,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_cached_kernel(const float* 
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-      xv[k] = valid ? xp[(long long)(cs + 4 * k) * HW] : 0.0f;
+      xv[k] = valid ? xp[(long long)(vs + VW * k) * HW] : 0.0f;
       s += xv[k];
     }
-    red[cs][lane] = s;
+    red[vs][px] = s;
     __syncthreads();
-    const float m = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)C;
+    const float m = ln_sum_waves<VW>(red, px) / (float)C;
     __syncthreads();
     float v = 0.0f;
 #pragma unroll
@@ -336,37 +372,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_cached_kernel(const float* 
       const float dd = xv[k] - m;
       v += dd * dd;
     }
-    red[cs][lane] = v;
+    red[vs][px] = v;
     __syncthreads();
-    const float r = rsqrtf(((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (float)C + eps);
+    const float r = rsqrtf(ln_sum_waves<VW>(red, px) / (float)C + eps);
     __syncthreads();
     if (valid) {
-      if (cs == 0 && mean) { mean[i] = m; rstd[i] = r; }
+      if (vs == 0 && mean) { mean[i] = m; rstd[i] = r; }
       float* yp = y + n * ybs + p;
 #pragma unroll
       for (int k = 0; k < CPT; ++k) {
-        const int c = cs + 4 * k;
+        const int c = vs + VW * k;
         yp[(long long)c * HW] = (xv[k] - m) * r * gamma[c] + beta[c];
       }
     }
   }
 }
-template <int CPT>
-__global__ __launch_bounds__(256) void layernorm_bwd_cached_kernel(const float* __restrict__ x, long long xbs,
-                                                                   const float* __restrict__ dy, long long dbs,
-                                                                   const float* __restrict__ gamma,
-                                                                   const float* __restrict__ mean,
-                                                                   const float* __restrict__ rstd,
-                                                                   float* __restrict__ dx, long long dxbs, int N,
-                                                                   int HW, int accum, const float* __restrict__ extra,
-                                                                   long long ebs) {
-  constexpr int C = 4 * CPT;
-  __shared__ float red[2][4][64];
-  const int lane = threadIdx.x & 63, cs = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+template <int CPT, int NW, bool FUSE>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_cached_kernel(const float* __restrict__ x, long long xbs,
+                                                                      const float* __restrict__ dy, long long dbs,
+                                                                      const float* __restrict__ gamma,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ rstd,
+                                                                      float* __restrict__ dx, long long dxbs, int N,
+                                                                      int HW, int accum, const float* __restrict__ extra,
+                                                                      long long ebs, float* __restrict__ pws) {
+  constexpr int VW = NW, LW = 64, C = VW * CPT;
+  __shared__ float red[2][VW][LW];
+  const int lane = threadIdx.x & 63, px = lane;
+  const int vs = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long total = (long long)N * HW;
-  const long long ntiles = (total + 63) / 64;
+  const long long ntiles = (total + LW - 1) / LW;
+  float ag[FUSE ? CPT : 1], ab[FUSE ? CPT : 1];   // parameter-gradient partials of this lane's pixels
+#pragma unroll
+  for (int k = 0; k < (FUSE ? CPT : 1); ++k) ag[k] = ab[k] = 0.0f;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long i = tile * 64 + lane;
+    const long long i = tile * LW + px;
     const bool valid = i < total;
     const int n = valid ? (int)(i / HW) : 0, p = valid ? (int)(i - (long long)n * HW) : 0;
     const float* xp = x + n * xbs + p;
@@ -376,28 +416,50 @@ __global__ __launch_bounds__(256) void layernorm_bwd_cached_kernel(const float* 
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-      const int c = cs + 4 * k;
+      const int c = vs + VW * k;
       xh[k] = valid ? (xp[(long long)c * HW] - m) * r : 0.0f;
-      gg[k] = valid ? gp[(long long)c * HW] * gamma[c] : 0.0f;
+      const float graw = valid ? gp[(long long)c * HW] : 0.0f;
+      if constexpr (FUSE) {
+        ag[k] += graw * xh[k];
+        ab[k] += graw;
+      }
+      gg[k] = graw * gamma[c];
       s1 += gg[k];
       s2 += gg[k] * xh[k];
     }
-    red[0][cs][lane] = s1;
-    red[1][cs][lane] = s2;
+    red[0][vs][px] = s1;
+    red[1][vs][px] = s2;
     __syncthreads();
-    s1 = ((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane])) / (float)C;
-    s2 = ((red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane])) / (float)C;
+    s1 = ln_sum_waves<VW>(red[0], px) / (float)C;
+    s2 = ln_sum_waves<VW>(red[1], px) / (float)C;
     __syncthreads();
     if (valid) {
       float* dp = dx + n * dxbs + p;
       const float* ep = extra ? extra + n * ebs + p : nullptr;
 #pragma unroll
       for (int k = 0; k < CPT; ++k) {
-        const int c = cs + 4 * k;
+        const int c = vs + VW * k;
         float v = r * (gg[k] - s1 - xh[k] * s2);
         if (ep) v += ep[(long long)c * HW];
         if (accum) v += dp[(long long)c * HW];
         dp[(long long)c * HW] = v;
+      }
+    }
+  }
+  if constexpr (FUSE) {
+    const int S = gridDim.x;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      float a = ag[k], b = ab[k];
+#pragma unroll
+      for (int o = LW / 2; o >= 1; o >>= 1) {   // within the virtual wave's LW lanes
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+      }
+      if (px == 0) {
+        const int c = vs + VW * k;
+        pws[(long long)blockIdx.x * C + c] = a;
+        pws[((long long)S + blockIdx.x) * C + c] = b;
       }
     }
   }
@@ -784,12 +846,13 @@ int icm_layernorm_fwd(const float* x, int64_t x_bs, const float* gamma, const fl
   if (!x || !gamma || !beta || !y || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
   const long long tiles = ((long long)N * HW + 63) / 64;
   const dim3 grid((unsigned)std::min<long long>(tiles, 256 * 16));
-#define ICM_LN_FWD(CPT)                                                                                              \
-  hipLaunchKernelGGL(layernorm_fwd_cached_kernel<CPT>, grid, dim3(256), 0, ST, x, (long long)x_bs, gamma, beta, y,   \
-                     (long long)y_bs, mean, rstd, N, HW, eps)
-  if (C == 48) ICM_LN_FWD(12);
-  else if (C == 96) ICM_LN_FWD(24);
-  else if (C == 192) ICM_LN_FWD(48);
+#define ICM_LN_FWD(CPT, NW)                                                                                          \
+  hipLaunchKernelGGL((layernorm_fwd_cached_kernel<CPT, NW>), grid, dim3(64 * NW), 0, ST, x, (long long)x_bs, gamma,   \
+                     beta, y, (long long)y_bs, mean, rstd, N, HW, eps)
+  if (C == 48) ICM_LN_FWD(12, 4);
+  else if (C == 96) ICM_LN_FWD(24, 4);
+  else if (C == 192) ICM_LN_FWD(24, 8);
+  else if (C == 384) ICM_LN_FWD(48, 8);
   else
     hipLaunchKernelGGL(layernorm_fwd_kernel, grid, dim3(256), 0, ST, x, (long long)x_bs, gamma, beta, y, (long long)y_bs,
                        mean, rstd, N, C, HW, eps);
@@ -802,23 +865,40 @@ int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
                       int N, int C, int HW, int accum_dx, int accum_params, const float* dx_extra, int64_t dx_extra_bs,
                       float* ws, int64_t ws_floats, void* stream) {
   if (!x || !dy || !gamma || !mean || !rstd || N <= 0 || C <= 0 || HW <= 0) return ICM_ERR_ARG;
+  const bool cached = C == 48 || C == 96 || C == 192 || C == 384;
+  bool params_done = false;
   if (dx) {
     const long long tiles = ((long long)N * HW + 63) / 64;
-    const dim3 grid((unsigned)std::min<long long>(tiles, 256 * 16));
-#define ICM_LN_BWD(CPT)                                                                                              \
-  hipLaunchKernelGGL(layernorm_bwd_cached_kernel<CPT>, grid, dim3(256), 0, ST, x, (long long)x_bs, dy,               \
+    long long nblk = std::min<long long>(tiles, 256 * 16);
+    // parameter gradients ride on the same pass when the workspace holds one partial row per workgroup
+    float* pws = nullptr;
+    static const bool nofuse = [] { const char* e = getenv("ICM_LN_NOFUSE"); return e && atoi(e) != 0; }();   // measurement only
+    if (!nofuse && cached && C <= 192 && dgamma && dbeta && ws && ws_floats >= 2LL * 64 * C) {
+      nblk = std::min<long long>(std::min<long long>(nblk, 1024), ws_floats / (2LL * C));
+      pws = ws;
+    }
+    const dim3 grid((unsigned)nblk);
+#define ICM_LN_BWD(CPT, NW, FUSE)                                                                                    \
+  hipLaunchKernelGGL((layernorm_bwd_cached_kernel<CPT, NW, FUSE>), grid, dim3(64 * NW), 0, ST, x, (long long)x_bs, dy, \
                      (long long)dy_bs, gamma, mean, rstd, dx, (long long)dx_bs, N, HW, accum_dx, dx_extra,           \
-                     (long long)dx_extra_bs)
-    if (C == 48) ICM_LN_BWD(12);
-    else if (C == 96) ICM_LN_BWD(24);
-    else if (C == 192) ICM_LN_BWD(48);
+                     (long long)dx_extra_bs, pws)
+    if (C == 48) { if (pws) ICM_LN_BWD(12, 4, true); else ICM_LN_BWD(12, 4, false); }
+    else if (C == 96) { if (pws) ICM_LN_BWD(24, 4, true); else ICM_LN_BWD(24, 4, false); }
+    else if (C == 192) { if (pws) ICM_LN_BWD(24, 8, true); else ICM_LN_BWD(24, 8, false); }
+    else if (C == 384) ICM_LN_BWD(48, 8, false);
     else
       hipLaunchKernelGGL(layernorm_bwd_kernel, grid, dim3(256), 0, ST, x, (long long)x_bs, dy, (long long)dy_bs, gamma,
                          mean, rstd, dx, (long long)dx_bs, N, C, HW, accum_dx, dx_extra, (long long)dx_extra_bs);
 #undef ICM_LN_BWD
     ICM_CHECK_LAUNCH();
+    if (pws) {
+      hipLaunchKernelGGL(split_sum_finish_wave_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, ST, ws, dgamma, dbeta, C,
+                         (int)nblk, 2, accum_params);
+      ICM_CHECK_LAUNCH();
+      params_done = true;
+    }
   }
-  if (dgamma && dbeta) {
+  if (dgamma && dbeta && !params_done) {
     // enough pixel chunks to fill the chip whatever C is (C = 48 at the 128x128 level)
     const long long chunks = ((long long)N * HW + 4095) / 4096;
     long long S = std::max<long long>(1, std::min<long long>(chunks, (2048 + C - 1) / C));

@@ -1030,7 +1030,7 @@ def layernorm(tape, x, gamma, beta) -> torch.Tensor:
             if tape.wants(x):
                 rg = tape.take_res_grad(x, False)   # x + f(LN(x)): the identity-path term rides on this pass
                 dx, ax = tape.grad_for_write(x)
-            wsp = tape.red_ws(2 * (2048 + Cc), x.device)
+            wsp = tape.red_ws(2 * 1024 * Cc, x.device)   # one partial row of dgamma / dbeta per workgroup of the fused pass
             check(L.lib().icm_layernorm_bwd(ptr(x), bs(x), ptr(dy), bs(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
                                             bs(dx), ptr(gg), ptr(gb_), N, Cc, HW, ax, ap, ptr(rg), bs(rg), ptr(wsp),
                                             wsp.numel(), tape.st), "layernorm_bwd")

@@ -52,8 +52,13 @@ def run_tape(fn, x, P, g):
     return y, tape.grad_of(xd), grads
 
 
-@pytest.mark.parametrize("shape,sliced", [((2, 48, 12, 8), False), ((3, 384, 4, 4), False), ((2, 96, 8, 8), True)])
+@pytest.mark.parametrize("shape,sliced", [((2, 48, 12, 8), False), ((3, 384, 4, 4), False), ((2, 96, 8, 8), True),
+                                          ((2, 192, 40, 40), False), ((4, 48, 64, 64), False), ((2, 384, 24, 20), False),
+                                          ((1, 40, 9, 7), False)])
 def test_layernorm_vs_torch(shape, sliced):
+    """C = 48 / 96 / 192: register-cached kernels with the parameter gradients fused into the input-gradient pass
+    (per-workgroup partials + fixed-order finish: the larger shapes span many workgroups); C = 384: cached, separate
+    parameter pass; C = 40: the generic kernels"""
     from icm_amd import engine as E
     N, C, H, Wd = shape
     x = W._u("ln.x", shape, -2.0, 3.0)
