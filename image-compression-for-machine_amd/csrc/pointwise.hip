@@ -743,7 +743,10 @@ int icm_channel_sum(const float* x, int64_t x_bs, int N, int C, int HW, float* o
   hipLaunchKernelGGL(channel_sum_kernel, dim3(C, (unsigned)S), dim3(256), 0, ST, x, (long long)x_bs, N, C, HW, out, ws,
                      accum);
   ICM_CHECK_LAUNCH();
-  if (S > 1) {
+  if (S > 4) {   // one wave per channel: the serial form is a chain of S dependent L2 round trips (~50 us at S = 32)
+    hipLaunchKernelGGL(split_sum_finish_wave_kernel, dim3((C + 3) / 4), dim3(256), 0, ST, ws, out, out, C, (int)S, 1, accum);
+    ICM_CHECK_LAUNCH();
+  } else if (S > 1) {
     hipLaunchKernelGGL(split_sum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, ws, out, out, C, (int)S, 1,
                        accum);
     ICM_CHECK_LAUNCH();
@@ -907,7 +910,11 @@ int icm_layernorm_bwd(const float* x, int64_t x_bs, const float* dy, int64_t dy_
     hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(C, (unsigned)S), dim3(256), 0, ST, x, (long long)x_bs, dy,
                        (long long)dy_bs, mean, rstd, dgamma, dbeta, ws, N, C, HW, accum_params);
     ICM_CHECK_LAUNCH();
-    if (S > 1) {
+    if (S > 4) {
+      hipLaunchKernelGGL(split_sum_finish_wave_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, ST, ws, dgamma, dbeta, C,
+                         (int)S, 2, accum_params);
+      ICM_CHECK_LAUNCH();
+    } else if (S > 1) {
       hipLaunchKernelGGL(split_sum_finish_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ST, ws, dgamma, dbeta, C,
                          (int)S, 2, accum_params);
       ICM_CHECK_LAUNCH();
