@@ -127,10 +127,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(const ConvDesc d) {
 struct Cfg1x1 {
   int tco, tpx;
   void (*fn)(const ConvDesc);
+  float eff;   // relative throughput of a wave of this tile shape when the chip is full (loads per MFMA; measured,
+               // profiles/r03_conv1x1_ablation.txt)
 };
 static const Cfg1x1 kCfgs1x1[] = {
-    {6, 1, conv1x1_kernel<6, 1>}, {5, 1, conv1x1_kernel<5, 1>}, {4, 1, conv1x1_kernel<4, 1>},
-    {3, 2, conv1x1_kernel<3, 2>}, {2, 2, conv1x1_kernel<2, 2>}, {1, 2, conv1x1_kernel<1, 2>},
+    {6, 1, conv1x1_kernel<6, 1>, 1.0f},  {5, 1, conv1x1_kernel<5, 1>, 1.0f}, {4, 1, conv1x1_kernel<4, 1>, 0.97f},
+    {3, 2, conv1x1_kernel<3, 2>, 1.0f},  {2, 2, conv1x1_kernel<2, 2>, 0.7f}, {1, 2, conv1x1_kernel<1, 2>, 0.6f},
+    {3, 1, conv1x1_kernel<3, 1>, 0.95f}, {2, 1, conv1x1_kernel<2, 1>, 0.6f},   // more, smaller wave tiles
 };
 
 int run_conv1x1(const icm_conv_args* arr, int ngroups, long long wp_off, int g_force_1x1, hipStream_t stream) {
@@ -140,13 +143,27 @@ int run_conv1x1(const icm_conv_args* arr, int ngroups, long long wp_off, int g_f
   if (a.OH != a.H || a.OW != a.W) return -1;
   const int ncot = cdiv(a.Cout, 32);
   const long long NP = (long long)a.N * a.H * a.W;
+  // Tile shape: no padded co tiles if avoidable; among those, the shape that keeps the chip busiest.  Every wave is
+  // independent, so a launch wants >= 2 waves per SIMD (2 048): the stf Linear layers on 32x32 maps (16 384 pixels) give
+  // the 192-co x 32-px tile only 512 waves -- half the SIMDs idle, the other half one wave each (768 -> 192: 79 us;
+  // with 96-co tiles 59 us).  score = min(waves, 2 048) x the shape's full-chip efficiency; ties: the earlier (larger).
   int best = -1, best_pad = 1 << 30;
-  for (int i = 0; i < (int)(sizeof(kCfgs1x1) / sizeof(kCfgs1x1[0])); ++i) {
-    const int padded = cdiv(ncot, kCfgs1x1[i].tco) * kCfgs1x1[i].tco;
-    if (padded < best_pad) {   // ties: the earlier (larger) co tile reads the activations fewer times
-      best_pad = padded;
+  const int ncfg = (int)(sizeof(kCfgs1x1) / sizeof(kCfgs1x1[0]));
+  for (int i = 0; i < ncfg; ++i) best_pad = std::min(best_pad, cdiv(ncot, kCfgs1x1[i].tco) * kCfgs1x1[i].tco);
+  float best_score = -1.0f;
+  for (int i = 0; i < ncfg; ++i) {
+    const Cfg1x1& k = kCfgs1x1[i];
+    if (cdiv(ncot, k.tco) * k.tco != best_pad) continue;
+    const long long waves = ((NP + 32 * k.tpx - 1) / (32 * k.tpx)) * cdiv(ncot, k.tco) * ngroups;
+    const float score = (float)std::min<long long>(waves, 2048) * k.eff;
+    if (score > best_score) {
+      best_score = score;
       best = i;
     }
+  }
+  {
+    static const int force = getenv("ICM_1X1_CFG") ? atoi(getenv("ICM_1X1_CFG")) : -1;   // measurement only
+    if (force >= 0 && force < (int)(sizeof(kCfgs1x1) / sizeof(kCfgs1x1[0]))) best = force;
   }
   const Cfg1x1& c = kCfgs1x1[best];
   const int ncb = cdiv(ncot, c.tco);

@@ -17,6 +17,13 @@ CASES = [  # name, N, Cin, H, W, Cout, members, materialise gelu (y2), residual
     ("gdn 192->192 @128", 16, 192, 128, 128, 192, 1, False, False),
     ("qkv 192->576 @64", 16, 192, 64, 64, 576, 1, False, False),
     ("proj 192->192 @64", 16, 192, 64, 64, 192, 1, False, False),
+    ("stf fc2 768->192 @32", 16, 768, 32, 32, 192, 1, False, True),
+    ("stf fc1 192->768 @32", 16, 192, 32, 32, 768, 1, False, False),
+    ("stf proj 192->192 @32", 16, 192, 32, 32, 192, 1, False, True),
+    ("stf qkv 192->576 @32", 16, 192, 32, 32, 576, 1, False, False),
+    ("stf fc2 384->96 @64", 16, 384, 64, 64, 96, 1, False, True),
+    ("stf proj 96->96 @64", 16, 96, 64, 64, 96, 1, False, True),
+    ("stf fc2 1536->384 @16", 16, 1536, 16, 16, 384, 1, False, True),
     ("RU 160->320 @16 x2", 16, 160, 16, 16, 320, 2, True, True),
     ("RU 320->160 @16 x2", 16, 320, 16, 16, 160, 2, True, False),
 ]
