@@ -487,14 +487,21 @@ __global__ __launch_bounds__(512, 2) void wgrad_tap9_kernel(const WgDesc d) {
 // WA x WB groups of 3 x 3 tiles and the 8 / (WA * WB) waves of a group split the pixel pairs (kp = wk mod WK) and fold
 // their partial sums through LDS at the end (fixed order).  The bias gradient comes from the A fragments of the wb == 0
 // waves, folded over the K split the same way.
-template <int TA, int TB, int WA, int WB>
+// V4 (64-pixel tiles, OW % 4 == 0): 16-byte DMA, FOUR channel rows per instruction -- (TA + TB) * 8 staging instructions
+// per tile instead of (TA + TB) * 32.  The address path charges per instruction, not per byte, and at one
+// 256-byte row per instruction the 288 DMAs of a 192 x 96 block took as long as its 576 MFMAs per SIMD (matrix pipe 38 %
+// busy).  A 16-byte DMA writes LDS linearly (base + 16 * lane), so rows are 64 floats apart with no padding; the bank
+// spread comes from rotating row r by 4 * (r mod 16) floats instead, which the per-lane GLOBAL address absorbs for free
+// (lane (s, q) of an instruction loads pixels 4 (q - r mod 16) mod 64 ... of row r = 4 i + s) and costs the fragment
+// reads one add + and per pixel pair (element (r, p) sits at 64 r + ((p + 4 (r mod 16)) mod 64); two-way conflicts).
+template <int TA, int TB, int WA, int WB, bool V4>
 __global__ __launch_bounds__(512, 2) void wgrad_dma1_kernel(const WgDesc d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   static_assert(TA == 3 * WA && TB == 3 * WB && (WA * WB == 1 || WA * WB == 2 || WA * WB == 4), "3 x 3 tiles per wave");
   constexpr int WK = 8 / (WA * WB);
   const PatchGeom& pg = d.pg;
-  const int npx = 1 << d.lgNPX, grow = npx + 1;
-  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * pg.CS;
+  const int npx = 1 << d.lgNPX, grow = V4 ? 64 : npx + 1, brow = V4 ? 64 : pg.CS;
+  const int gs_sz = TA * 32 * grow, gb_sz = TB * 32 * brow;
   const int bufsz = gs_sz + gb_sz;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -514,6 +521,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma1_kernel(const WgDesc d) {
   const int OHW = d.OH * d.OW;
   const long long HW = (long long)pg.H * pg.W;
   const float* zero = icm_zero_page + lane;
+  const float* zero4 = icm_zero_page + 4 * lane;
 
   // both operands of a 1x1 stride-1 problem are [channel][pixel of the tile]: one channel row per DMA instruction
   auto stage = [&](int it) {
@@ -529,7 +537,27 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma1_kernel(const WgDesc d) {
     const bool pv = n < pg.N && oy < d.OH && ox < d.OW;
     const float* abase = G.gs + ((long long)n * d.gs_bs + oy * d.OW + ox);
     const float* bbase = G.gb + ((long long)n * pg.bs + oy * pg.W + ox);
-    if (lane < npx) {
+    if constexpr (V4) {
+      // instruction i covers rows 4 i .. 4 i + 3: lane = (row slot s = lane >> 4, LDS piece q = lane & 15)
+      const int s = lane >> 4, q = lane & 15;
+      for (int i = wave; i < (TA + TB) * 8; i += 8) {
+        const bool isa = i < TA * 8;
+        const int r = (isa ? i : i - TA * 8) * 4 + s;                 // row of its operand
+        const int px = ((q - (r & 15)) & 15) * 4;                     // first of the 4 tile pixels this lane moves
+        const int tx4 = px & TWm, ty4 = (px >> d.lgTW) & THm, ti4 = px >> (d.lgTW + d.lgTH);
+        const int n4 = n0 + ti4, oy4 = oy0 + ty4, ox4 = ox0 + tx4;
+        const bool pv4 = n4 < pg.N && oy4 < d.OH && ox4 < d.OW;
+        const float* src;
+        if (isa) {
+          const int a = a0 + r;
+          src = (pv4 && a < d.Ca) ? G.gs + ((long long)n4 * d.gs_bs + (long long)a * OHW + oy4 * d.OW + ox4) : zero4;
+        } else {
+          const int c = b0 + r;
+          src = (pv4 && c < pg.C) ? G.gb + ((long long)n4 * pg.bs + (long long)c * HW + oy4 * pg.W + ox4) : zero4;
+        }
+        __builtin_amdgcn_global_load_lds(src, (isa ? gsT : gbP) + (isa ? i : i - TA * 8) * 256, 16, 0, 0);
+      }
+    } else if (lane < npx) {
       for (int r = wave; r < TA * 32; r += 8) {
         const int a = a0 + r;
         __builtin_amdgcn_global_load_lds((pv && a < d.Ca) ? abase + (long long)a * OHW : zero, gsT + r * grow, 4, 0, 0);
@@ -546,7 +574,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma1_kernel(const WgDesc d) {
   const int wa = wsp / WB, wb = wsp % WB;
   int boffs[3];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) boffs[u] = ((wb * 3 + u) * 32 + l31) * pg.CS + h;
+  for (int u = 0; u < 3; ++u) boffs[u] = ((wb * 3 + u) * 32 + l31) * brow + (V4 ? 0 : h);
+  const int rot = 4 * (l31 & 15) + h;   // V4: column of pixel p in this lane's rows = (p + rot) & 63
   f32x16 acc[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
@@ -562,13 +591,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma1_kernel(const WgDesc d) {
     if (it + 1 < niter) stage(it + 1);
     const float* gsT = smem + (it & 1) * bufsz;
     const float* gbP = gsT + gs_sz;
-    const float* arow = gsT + (wa * 3 * 32 + l31) * grow + h;
+    const float* arow = gsT + (wa * 3 * 32 + l31) * grow + (V4 ? 0 : h);
     float avA[3], bvA[3], avB[3], bvB[3];
     auto fetch = [&](float (&av)[3], float (&bv)[3], int kn) {
+      const int col = V4 ? ((2 * kn + rot) & 63) : 2 * kn;
 #pragma unroll
-      for (int u = 0; u < 3; ++u) av[u] = arow[u * 32 * grow + 2 * kn];
+      for (int u = 0; u < 3; ++u) av[u] = arow[u * 32 * grow + col];
 #pragma unroll
-      for (int u = 0; u < 3; ++u) bv[u] = gbP[boffs[u] + 2 * kn];
+      for (int u = 0; u < 3; ++u) bv[u] = gbP[boffs[u] + col];
     };
     auto mma = [&](const float (&av)[3], const float (&bv)[3]) {
 #pragma unroll
@@ -1247,10 +1277,15 @@ static int wgrad_grouped(const icm_wgrad_args* arr, int n, hipStream_t stream) {
   }
   const long long nblk = (long long)p.natile * p.nbtile * p.ngroups * p.nsplit;
   void (*fn)(const WgDesc) = nullptr;
-  if (p.ws == 11) fn = wgrad_dma1_kernel<6, 6, 2, 2>;
-  else if (p.ws == 12) fn = wgrad_dma1_kernel<3, 6, 1, 2>;
-  else if (p.ws == 13) fn = wgrad_dma1_kernel<6, 3, 2, 1>;
-  else if (p.ws == 14) fn = wgrad_dma1_kernel<3, 3, 1, 1>;
+  static const bool dma1_v4_off = [] { const char* e = getenv("ICM_WG_DMA1_V4"); return e && atoi(e) == 0; }();   // measurement only
+  bool v4dma = !dma1_v4_off && p.ws >= 11 && p.ws <= 14 && p.lgNPX == 6 && p.lgTW >= 2 && (a->OW % 4) == 0 &&
+               (a->gs_bs % 4) == 0 && (a->gb_bs % 4) == 0;
+  for (int i = 0; i < n && v4dma; ++i)
+    v4dma = ((reinterpret_cast<uintptr_t>(arr[i].gs) | reinterpret_cast<uintptr_t>(arr[i].gb)) & 15) == 0;
+  if (p.ws == 11) fn = v4dma ? wgrad_dma1_kernel<6, 6, 2, 2, true> : wgrad_dma1_kernel<6, 6, 2, 2, false>;
+  else if (p.ws == 12) fn = v4dma ? wgrad_dma1_kernel<3, 6, 1, 2, true> : wgrad_dma1_kernel<3, 6, 1, 2, false>;
+  else if (p.ws == 13) fn = v4dma ? wgrad_dma1_kernel<6, 3, 2, 1, true> : wgrad_dma1_kernel<6, 3, 2, 1, false>;
+  else if (p.ws == 14) fn = v4dma ? wgrad_dma1_kernel<3, 3, 1, 1, true> : wgrad_dma1_kernel<3, 3, 1, 1, false>;
   else if (p.ws == 10) fn = wgrad_tap9_kernel<3, 1, 3>;
   else if (p.ws == 8) fn = wgrad_tap9_kernel<3, 3>;
   else if (p.ws == 9) fn = wgrad_tap9_kernel<2, 2>;

@@ -306,7 +306,8 @@ __device__ __forceinline__ void stage_planes(const float* __restrict__ src, cons
 // e = lane + 64 j of a channel plane lands at slab + e, exactly where a wave-wide DMA puts lane `lane` of its j-th
 // instruction.  Padding / out-of-range elements read from a zero page; lanes beyond the plane are masked off (EXEC).
 // The issuing wave must drain vmcnt before the barrier that publishes the stage (barriers do not wait for DMAs).
-static __device__ float icm_zero_page[64];   // zero-initialised when the code object is loaded (one copy per TU)
+static __device__ __attribute__((aligned(16))) float icm_zero_page[256];   // zero-initialised when the code object is loaded
+                                                                            // (one copy per TU; 16 bytes per lane for the wide DMAs)
 
 template <int NJR>
 __device__ __forceinline__ void stage_planes_dma_t(const float* __restrict__ src, const PlaneMap& m, const PatchGeom& g,
