@@ -95,11 +95,15 @@ __device__ __forceinline__ void store_half_e(const ConvDesc& d, const ConvPtrs& 
     }
     if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
       // materialised activation for the consumers of this pre-activation (forward only): y2 = gelu(y), of the value
-      // AFTER an accumulation (the launch that completes a partial sum materialises it)
+      // AFTER an accumulation (the launch that completes a partial sum materialises it).  y2 == y (inference: nobody
+      // reads the pre-activation again): only gelu(y) is stored.
       if (y2b) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (ok[q]) y2b[off[q]] = gelu_f(v[q]);
+        for (int q = 0; q < 8; ++q) {
+          const float gv = gelu_f(v[q]);
+          if (y2b == yb) v[q] = gv;
+          else if (ok[q]) y2b[off[q]] = gv;
+        }
       }
     }
 #pragma unroll
@@ -189,8 +193,11 @@ __device__ __forceinline__ void epi_finish(const ConvDesc& d, const ConvPtrs& P,
   if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
     if (y2b) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (R.ok[q]) y2b[R.off[q]] = gelu_f(v[q]);
+      for (int q = 0; q < 8; ++q) {
+        const float gv = gelu_f(v[q]);
+        if (y2b == yb) v[q] = gv;   // y2 == y: only the activated value is stored (see store_half_e)
+        else if (R.ok[q]) y2b[R.off[q]] = gv;
+      }
     }
   }
 #pragma unroll

@@ -61,7 +61,11 @@ __device__ __forceinline__ void wino_finish(const WinoDesc& d, const ConvPtrs& P
   }
   if (d.accum) v += P.y[off];
   if constexpr (EPI == ICM_EPI_NONE || EPI == ICM_EPI_RES || EPI == ICM_EPI_RES_GELU) {
-    if (P.y2) P.y2[off] = gelu_f(v);
+    if (P.y2) {
+      const float gv = gelu_f(v);
+      if (P.y2 == P.y) v = gv;   // y2 == y: only the activated value is stored (conv_common.h)
+      else P.y2[off] = gv;
+    }
   }
   P.y[off] = v;
 }

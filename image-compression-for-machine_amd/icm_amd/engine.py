@@ -46,6 +46,9 @@ _WINO_WG_BATCH = float(_os.environ.get("ICM_WINO_WG_BATCH", "4"))
 USE_WINO_WGRAD = _os.environ.get("ICM_WINO_WGRAD", "1") != "0"
 # stride-1 Conv2d layers with <= 8 output channels (stf end_conv[2]) as a dense (channel, tap)-row GEMM + col2im
 THIN_OUT = _os.environ.get("ICM_THIN_OUT", "1") != "0"
+# inference (no gradients): a layer whose consumers all read gelu(y) stores ONLY gelu(y) (the kernels take y2 == y as
+# "store the activated value"): the pre-activation is needed by the backward pass alone
+EVAL_INPLACE_ACT = _os.environ.get("ICM_EVAL_INPLACE_ACT", "1") != "0"
 # input transform of the Winograd convolutions as its own launch (one per distinct input tensor of a launch) + LDS-DMA
 # staging in the convolution kernel, instead of gather + transform by the kernel's loader waves per co-block
 WINO_PRE = _os.environ.get("ICM_WINO_PRE", "1") != "0"
@@ -579,7 +582,10 @@ def conv2d(tape: Tape, xv: VT, w, b, *, stride=1, pad=0, transposed=False, outpu
         epi, aux = EPI_LRP, lrp_aux
         y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
     elif act_out and _MATERIALIZE and N * OH * OW >= _MAT_MIN_PIXELS:
-        y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
+        if EVAL_INPLACE_ACT and not tape.need_grad and out is None:
+            y2 = y     # inference: y holds gelu(pre-activation); VT(y, GELU) consumers read it as is (tape.mat)
+        else:
+            y2 = torch.empty(oshape, dtype=torch.float32, device=x.device)
         tape.mat[_key(y)] = y2
     conv_launch(tape, xf, wp, b, y, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=stride, pad=pad, transposed=transposed,
                 OH=OH, OW=OW, pro_act=actf, epi=epi, res=resv, aux=aux, y2=y2, ps=pixel_shuffle, algo=wino)
@@ -811,7 +817,10 @@ def conv2d_group(tape: Tape, xvs, ws, bs_, *, pad=1, outs=None, lrp_auxs=None, r
         else:
             resf, epi = [r.t for r in ress], (EPI_RES_GELU if ress[0].act == ACT_GELU else EPI_RES)
     if act_out and _MATERIALIZE and not lrp and N * OH * OW >= _MAT_MIN_PIXELS:
-        y2s = [new(oshape, x0.device) for _ in range(n)]
+        if EVAL_INPLACE_ACT and not tape.need_grad and outs is None:
+            y2s = list(ys)   # inference: only gelu(y) is stored (see conv2d)
+        else:
+            y2s = [new(oshape, x0.device) for _ in range(n)]
         for y, y2 in zip(ys, y2s):
             tape.mat[_key(y)] = y2
     conv_launch_grouped(tape, xfs, wps, bs_, ys, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride=1, pad=pad,
@@ -940,15 +949,17 @@ def gdn(tape: Tape, x, beta, gamma, inverse: bool, beta_min: float = 1e-6) -> to
 
 
 # ------------------------------------------------------------------------------------------------ attention gate
-def residual_unit(tape, xv: VT, P, p) -> VT:
-    """layers/layers.py:52-72 with virtual GELUs: returns VT(pre, GELU)."""
+def residual_unit(tape, xv: VT, P, p, last: bool = False) -> VT:
+    """layers/layers.py:52-72 with virtual GELUs: returns VT(pre, GELU).  last: the unit in front of the gate, whose
+    output the gate kernel reads as a pre-activation -- in inference it is not stored activated."""
     u1 = conv2d(tape, xv, P[p + ".conv.0.weight"], P[p + ".conv.0.bias"], act_out=True)
     u2 = conv2d(tape, VT(u1, ACT_GELU), P[p + ".conv.2.weight"], P[p + ".conv.2.bias"], pad=1, act_out=True)
-    u3 = conv2d(tape, VT(u2, ACT_GELU), P[p + ".conv.4.weight"], P[p + ".conv.4.bias"], res=xv, act_out=True)
+    u3 = conv2d(tape, VT(u2, ACT_GELU), P[p + ".conv.4.weight"], P[p + ".conv.4.bias"], res=xv,
+                act_out=tape.need_grad or not last)
     return VT(u3, ACT_GELU)
 
 
-def residual_unit_pair(tape, xa: VT, xb: VT, P, pa, pb):
+def residual_unit_pair(tape, xa: VT, xb: VT, P, pa, pb, last: bool = False):
     """the same ResidualUnit step of the two independent gate branches (conv_a[j], conv_b[j+1]; layers.py:75-81) as
     grouped launches: the 4 096-pixel gates (dim 320) fill only half the chip one branch at a time"""
     u1 = conv2d_group(tape, [xa, xb], [P[pa + ".conv.0.weight"], P[pb + ".conv.0.weight"]],
@@ -958,7 +969,8 @@ def residual_unit_pair(tape, xa: VT, xb: VT, P, pa, pb):
                       [P[pa + ".conv.2.bias"], P[pb + ".conv.2.bias"]], pad=1, act_out=True)
     u3 = conv2d_group(tape, [VT(u2[0], ACT_GELU), VT(u2[1], ACT_GELU)],
                       [P[pa + ".conv.4.weight"], P[pb + ".conv.4.weight"]],
-                      [P[pa + ".conv.4.bias"], P[pb + ".conv.4.bias"]], pad=0, ress=[xa, xb], act_out=True)
+                      [P[pa + ".conv.4.bias"], P[pb + ".conv.4.bias"]], pad=0, ress=[xa, xb],
+                      act_out=tape.need_grad or not last)
     return VT(u3[0], ACT_GELU), VT(u3[1], ACT_GELU)
 
 
@@ -1113,12 +1125,12 @@ def attention_gate(tape, x, P, p, heads, ws, shift) -> torch.Tensor:
     b = VT(window_attention(tape, x, P, p + ".conv_b.0", heads, ws, shift))
     if PAIR_GATE_BRANCHES:
         for i in range(3):   # conv_a[i] and conv_b[i + 1] are independent and shape-identical
-            a, b = residual_unit_pair(tape, a, b, P, f"{p}.conv_a.{i}", f"{p}.conv_b.{i + 1}")
+            a, b = residual_unit_pair(tape, a, b, P, f"{p}.conv_a.{i}", f"{p}.conv_b.{i + 1}", last=i == 2)
     else:
         for i in range(3):
-            a = residual_unit(tape, a, P, f"{p}.conv_a.{i}")
+            a = residual_unit(tape, a, P, f"{p}.conv_a.{i}", last=i == 2)
         for i in (1, 2, 3):
-            b = residual_unit(tape, b, P, f"{p}.conv_b.{i}")
+            b = residual_unit(tape, b, P, f"{p}.conv_b.{i}", last=i == 3)
     b4 = conv2d(tape, b, P[p + ".conv_b.4.weight"], P[p + ".conv_b.4.bias"])
     out = new(x)
     xc = x if x.is_contiguous() else x.contiguous()

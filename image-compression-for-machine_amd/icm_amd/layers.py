@@ -182,7 +182,8 @@ class Win_noShift_Attention(nn.Module):
 
             def forward(self, x):
                 def f(tape, P, t):
-                    v = E.residual_unit(tape, VT(t), {"u." + k: p for k, p in P.items()}, "u")
+                    # (last=True: this module applies the closing GELU itself, so it wants the pre-activation)
+                    v = E.residual_unit(tape, VT(t), {"u." + k: p for k, p in P.items()}, "u", last=True)
                     out = E.new(t)
                     E.check(E.L.lib().icm_gelu_fwd(E.ptr(v.t), E.ptr(out), t.numel(), tape.st), "gelu")
                     if tape.need_grad:

@@ -839,12 +839,27 @@ def test_conv_ks8_fused_neighbours():
         b = U("ks8.ps.b", (96,), -0.3, 0.3)
         ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), 2)
         min_px, E._MAT_MIN_PIXELS = E._MAT_MIN_PIXELS, 0      # materialise even this small launch
-        for cfg in (100, 101):
-            lib.icm_debug_force_conv_cfg(cfg)
-            tape = E.Tape(need_grad=False)
-            y = E.conv2d(tape, VT(x.to(dev())), w.to(dev()), b.to(dev()), pad=1, pixel_shuffle=2, act_out=True)
-            close(y, ref, what=f"pixel-shuffle store cfg {cfg}")
-            close(tape.mat[E._key(y)], F.gelu(ref), what=f"materialised gelu cfg {cfg}")
+        inplace = E.EVAL_INPLACE_ACT
+        try:
+            for cfg in (100, 101):
+                lib.icm_debug_force_conv_cfg(cfg)
+                E.EVAL_INPLACE_ACT = False      # two outputs: the pre-activation and its GELU
+                tape = E.Tape(need_grad=False)
+                y = E.conv2d(tape, VT(x.to(dev())), w.to(dev()), b.to(dev()), pad=1, pixel_shuffle=2, act_out=True)
+                close(y, ref, what=f"pixel-shuffle store cfg {cfg}")
+                close(tape.mat[E._key(y)], F.gelu(ref), what=f"materialised gelu cfg {cfg}")
+                E.EVAL_INPLACE_ACT = True       # inference default: only gelu(y) is stored, in y itself
+                tape = E.Tape(need_grad=False)
+                y = E.conv2d(tape, VT(x.to(dev())), w.to(dev()), b.to(dev()), pad=1, pixel_shuffle=2, act_out=True)
+                assert tape.mat[E._key(y)] is y
+                close(y, F.gelu(ref), what=f"activated-only store cfg {cfg}")
+                # ... and never when gradients are recorded (the backward pass needs the pre-activation)
+                tape = E.Tape(need_grad=True)
+                y = E.conv2d(tape, VT(x.to(dev())), w.to(dev()), b.to(dev()), pad=1, pixel_shuffle=2, act_out=True)
+                assert tape.mat[E._key(y)] is not y
+                close(y, ref, what=f"pre-activation kept for the backward pass cfg {cfg}")
+        finally:
+            E.EVAL_INPLACE_ACT = inplace
         E._MAT_MIN_PIXELS = min_px
     finally:
         lib.icm_debug_force_conv_cfg(-1)
@@ -1042,6 +1057,41 @@ def test_winograd_conv_vs_torch_and_direct(case, monkeypatch):
     close(outs["wino"][0], outs["direct"][0], tol=1e-5, what="wino vs direct fwd")
     close(outs["wino"][2], outs["direct"][2], tol=2e-5, what="wino vs direct dgrad")
     assert torch.equal(outs["wino"][3], outs["direct"][3])    # the weight gradient is the same (direct) kernel
+
+
+@pytest.mark.parametrize("case", [("ip.igemm", 2, 24, 12, 12, 40, 3, False), ("ip.1x1", 4, 96, 64, 64, 192, 1, False),
+                                  ("ip.wino", 4, 64, 16, 16, 64, 3, True), ("ip.group", 2, 40, 16, 16, 32, 3, False)])
+def test_inference_stores_only_the_activated_value(case, monkeypatch):
+    """need_grad=False + act_out: y2 == y is passed to the kernels and y holds gelu(conv(x)) (+ residual), for the staged
+    implicit-GEMM kernel, the independent-wave 1x1 kernel, the Winograd kernel and grouped launches; consumers that
+    wrap the result as VT(y, GELU) read it unchanged"""
+    from icm_amd import engine as E
+    from icm_amd.engine import VT
+    d = dev()
+    name, N, Cin, H, Wd, Cout, k, wino = case
+    monkeypatch.setattr(E, "_MAT_MIN_PIXELS", 0)
+    monkeypatch.setattr(E, "EVAL_INPLACE_ACT", True)
+    if wino:
+        monkeypatch.setattr(E, "_WINO_MIN_WORK", 0.0)
+        monkeypatch.setattr(E, "_WINO_MIN_CIN", 16)
+    else:
+        monkeypatch.setattr(E, "USE_WINO", False)
+    x = U(name + ".x", (N, Cin, H, Wd), -1.0, 1.0)
+    w = U(name + ".w", (Cout, Cin, k, k), -0.2, 0.2)
+    b = U(name + ".b", (Cout,), -0.3, 0.3)
+    r = U(name + ".r", (N, Cout, H, Wd), -1.0, 1.0)
+    ref = F.gelu(F.conv2d(x, w, b, padding=k // 2) + r)
+    tape = E.Tape(need_grad=False)
+    if name == "ip.group":
+        ys = E.conv2d_group(tape, [VT(x.to(d)), VT(x.to(d))], [w.to(d), w.to(d)], [b.to(d), b.to(d)], pad=k // 2,
+                            ress=[VT(r.to(d)), VT(r.to(d))], act_out=True)
+    else:
+        ys = [E.conv2d(tape, VT(x.to(d)), w.to(d), b.to(d), pad=k // 2, res=VT(r.to(d)), act_out=True)]
+    for y in ys:
+        assert tape.mat[E._key(y)] is y
+        close(y, ref, what=name + " activated-only store")
+        t, a = E._operand(tape, VT(y, E.ACT_GELU))
+        assert t is y and a == E.ACT_NONE
 
 
 def test_winograd_grouped_lrp_residual_and_blocked_map(monkeypatch):
