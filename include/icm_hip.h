@@ -71,7 +71,8 @@ typedef struct icm_conv_args {
   const float* res; int64_t res_bs;
   const float* aux; int64_t aux_bs;
   const float* aux2; int64_t aux2_bs;
-  float* y2; int64_t y2_bs;
+  float* y2; int64_t y2_bs;   /* second output (epi NONE / RES / RES_GELU: gelu(y); GDN: the norm; LRP: tanh); y2 == y with
+                               * y2_bs == y_bs: store ONLY gelu(y), in y (inference: nobody reads the pre-activation) */
   int accum;          /* y += result instead of y = result (gradient accumulation; with y2: y2 = gelu(y after the add)) */
   int pixel_shuffle;  /* 2: fuse nn.PixelShuffle(2) into the store (layers.py:34-38); y plane is (2*OH,2*OW), Cout/4 channels */
   /* blocked input-channel map (0 = none): logical channel c reads plane c + (c / x_seg_len) * x_seg_gap of x -- the
