@@ -170,7 +170,11 @@ int run_conv1x1(const icm_conv_args* arr, int ngroups, long long wp_off, int g_f
   const long long strips = (NP + 32 * c.tpx - 1) / (32 * c.tpx);
   // independent waves need >= one wave per SIMD to beat the split-K / co-resident tilings of the staged kernel
   static const long long kMinWaves = getenv("ICM_1X1_MIN_WAVES") ? atoll(getenv("ICM_1X1_MIN_WAVES")) : 1024;
-  if (g_force_1x1 < 0 && strips * ncb * ngroups < kMinWaves) return -1;
+  // (short contractions pay less for a half-empty chip than the staged kernel pays for its barriers: 320 -> 160 at 16x16
+  //  x 2 members, 640 waves: 24.9 us here against 29.7 us staged; 1 536 -> 384 on the same map is the other way round)
+  static const int kShortK = getenv("ICM_1X1_SHORT_K") ? atoi(getenv("ICM_1X1_SHORT_K")) : 384;
+  const long long need = a.Cin <= kShortK ? kMinWaves / 2 : kMinWaves;
+  if (g_force_1x1 < 0 && strips * ncb * ngroups < need) return -1;
   ConvDesc d;
   for (int gi = 0; gi < ICM_MAX_GROUPS; ++gi) {
     const icm_conv_args& s = arr[gi < ngroups ? gi : 0];
